@@ -1,0 +1,233 @@
+/* include/nbody.h — C ABI of libnbody_hip.so, the MI355X (gfx950) drop-in for the
+ * reference's pairwise-gravity + kick/drift path.
+ *
+ * The reference (7IBBE77S/nbodysim, paths relative to Nbodysim/) has no FFI: its
+ * boundary is the public surface of `class Simulation`
+ * (headers/Simulation.hpp:49-75): a constructor, `void step()`, and the public
+ * `std::vector<Body> bodies`, driven by one caller, `simulation_thread`
+ * (source/main.cpp:612-635).  Every entry point below names the piece of that
+ * surface it replaces.  Plain C types only: pointers, sizes, scalars.
+ *
+ * Error convention (the reference has none — void returns, no exceptions):
+ * int-returning functions give 0 on success and a negative NB_E* code on
+ * failure; pointer-returning functions give NULL; nb_last_error() holds the
+ * text for the calling thread.  A handle is not thread-safe (the reference's
+ * Simulation is single-caller too, main.cpp:621).
+ *
+ * There is NO CPU fallback: without a HIP device nb_create() fails with
+ * NB_ENODEVICE.
+ */
+#ifndef NBODY_H
+#define NBODY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_ABI_VERSION 1
+
+/* ---- particle record -------------------------------------------------------
+ * Bit-compatible with the reference's `struct alignas(16) Body`
+ * (headers/Body.hpp:6-13) built on `struct alignas(16) Vec2 {float x, y;}`
+ * (headers/Vec2.hpp:17-20).  The source comments claim 32 bytes; the real
+ * sizeof is 64 because each Vec2 is padded to 16 (measured with g++ 11.4 and
+ * clang 22 — tests/golden/layout.json).  Padding is indeterminate in the
+ * reference (Vec2's copy-ctor copies x,y only, Vec2.hpp:26); this library
+ * always writes it as zero and never reads it. */
+typedef struct nb_vec2 {
+    float x, y;
+    float _pad[2];
+} nb_vec2;
+
+typedef struct nb_body {
+    nb_vec2 pos;     /* offset  0  Body::pos    */
+    nb_vec2 vel;     /* offset 16  Body::vel    */
+    nb_vec2 acc;     /* offset 32  Body::acc    */
+    float   mass;    /* offset 48  Body::mass   */
+    float   radius;  /* offset 52  Body::radius (carried, unused by gravity) */
+    float   _pad[2];
+} nb_body;
+
+#if defined(__cplusplus)
+static_assert(sizeof(nb_vec2) == 16, "Vec2 is 16 bytes (Vec2.hpp:17)");
+static_assert(sizeof(nb_body) == 64, "Body is 64 bytes (Body.hpp:6)");
+static_assert(offsetof(nb_body, vel) == 16 && offsetof(nb_body, acc) == 32 &&
+              offsetof(nb_body, mass) == 48 && offsetof(nb_body, radius) == 52,
+              "Body field offsets");
+#else
+_Static_assert(sizeof(nb_vec2) == 16, "Vec2 is 16 bytes (Vec2.hpp:17)");
+_Static_assert(sizeof(nb_body) == 64, "Body is 64 bytes (Body.hpp:6)");
+_Static_assert(offsetof(nb_body, vel) == 16 && offsetof(nb_body, acc) == 32 &&
+               offsetof(nb_body, mass) == 48 && offsetof(nb_body, radius) == 52,
+               "Body field offsets");
+#endif
+
+/* ---- enums ---------------------------------------------------------------- */
+enum { NB_OK = 0, NB_EINVAL = -1, NB_ENODEVICE = -2, NB_EHIP = -3, NB_ENOMEM = -4,
+       NB_EIO = -5, NB_EFORMAT = -6, NB_ESTATE = -7 };
+
+/* arithmetic type of the device path */
+enum { NB_FP32 = 0,   /* the reference's type (everything is float, Vec2.hpp:20) */
+       NB_FP64 = 1 }; /* build extension (BASELINE config 5) */
+
+/* inverse square root flavour */
+enum { NB_RSQRT_EXACT = 0,   /* hardware v_rsq_f32 (fp32) / 1/sqrt (fp64): headline mode */
+       NB_RSQRT_QUAKE = 1 }; /* Quadtree::fast_inv_sqrt, Quadtree.hpp:106-111: reference arithmetic */
+
+/* order in which one particle's j-terms are summed */
+enum { NB_SUM_TILED = 0,       /* LDS-tiled, packed FP32, FMA-contracted: fast path */
+       NB_SUM_SEQUENTIAL = 1 };/* j ascending, one running sum, no FMA — the order of
+                                  Quadtree.hpp:134-144; with NB_RSQRT_QUAKE this is
+                                  bit-identical to the compiled reference */
+
+/* nb_params.extras bit flags: the non-gravity parts of Simulation::iterate */
+enum { NB_EXTRA_VCLAMP   = 1,   /* |v| <= 1000,            Simulation.hpp:133-137 */
+       NB_EXTRA_BOUNDARY = 2 }; /* soft boundary + damping, Simulation.hpp:140-155 */
+
+/* integrator */
+enum { NB_INTEGRATOR_KICK_DRIFT = 0, /* Simulation.hpp:129-131,160-163 (reference) */
+       NB_INTEGRATOR_KDK = 1 };      /* kick-drift-kick leapfrog (build extension) */
+
+/* ---- parameters ----------------------------------------------------------- */
+typedef struct nb_params {
+    uint32_t struct_size;  /* = sizeof(nb_params); set by nb_params_default */
+    float    eps;          /* softening length; reference: 1.0f (Simulation.hpp:59 -> Quadtree.hpp:19) */
+    float    dt;           /* default time step; reference: SIMULATION_DT = 0.01f (main.cpp:39) */
+    int32_t  precision;    /* NB_FP32 | NB_FP64 */
+    int32_t  rsqrt_mode;   /* NB_RSQRT_* */
+    int32_t  sum_order;    /* NB_SUM_* */
+    int32_t  integrator;   /* NB_INTEGRATOR_* */
+    int32_t  extras;       /* NB_EXTRA_* bit mask; 0 = pure gravity */
+    int32_t  device;       /* HIP device ordinal, -1 = current device */
+    int32_t  j_slices;     /* 0 = auto; >0 forces the number of j-slices of the force grid */
+    uint64_t i_begin;      /* first particle this handle integrates (sharding) */
+    uint64_t i_count;      /* number of particles it integrates; 0 = all n */
+    void    *stream;       /* hipStream_t to enqueue on, NULL = a private stream */
+    void    *pos_buffers[2];/* optional caller-owned device buffers for the two full-n
+                              position replicas (n * 2 * sizeof(real) bytes each, (x,y)
+                              interleaved) so that a host-side collective can fill them;
+                              NULL = allocated by the library */
+} nb_params;
+
+typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
+
+/* Fill *p with the reference's defaults (eps 1.0, dt 0.01, fp32, exact rsqrt, tiled sum). */
+void nb_params_default(nb_params *p);
+
+/* Replaces Simulation::Simulation() (Simulation.hpp:58-65) minus the hard-coded
+ * ICs: the caller supplies the n initial bodies (AoS, 64-B records); they are
+ * unpacked to SoA device arrays.  frame starts at 0. */
+nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *params);
+
+/* Releases everything (the reference relies on ~Simulation via shared_ptr, main.cpp:657). */
+void nb_destroy(nb_sim *s);
+
+/* Replaces Simulation::step() (Simulation.hpp:67-75) called nsteps times with
+ * time step dt (dt <= 0 -> params.dt; the reference reads the global
+ * SIMULATION_DT once per step, Simulation.hpp:69).  Each step = force
+ * evaluation at x_n (attract, :176) -> v += a dt -> x += v dt (iterate,
+ * :129-163), ++frame (:74).  collide() (:72) is NOT performed: it is not
+ * gravity and is a no-op for radius-0 bodies.  Work is ENQUEUED on
+ * the handle's stream; nb_wait / nb_sync / nb_energy order after it. */
+int nb_step(nb_sim *s, float dt, int nsteps);
+
+/* Block until all enqueued work of the handle is complete. */
+int nb_wait(nb_sim *s);
+
+/* Bring the host view up to date: writes the owned block (i_begin..i_begin+i_count)
+ * into out[0..i_count) — pos, vel, acc (of the last force evaluation), mass,
+ * radius, padding zeroed.  This is what makes `Simulation::bodies`
+ * (Simulation.hpp:54) coherent after step() for the snapshot copy at
+ * main.cpp:623-627. */
+int nb_sync(nb_sim *s, nb_body *out);
+
+/* Positions only (8 bytes/body instead of 64): the fast path for a viewer that
+ * only draws (main.cpp:623-627 consumer).  out holds 2*i_count floats (x,y).
+ * For NB_FP64 handles values are rounded to float. */
+int nb_sync_positions(nb_sim *s, float *out_xy);
+
+/* Push host-side edits of the bodies back (the reference's `bodies` is public
+ * and the GUI appends to it through SPAWN_QUEUE, main.cpp:43).  in holds the n
+ * bodies of the whole system. */
+int nb_upload(nb_sim *s, const nb_body *in);
+
+/* Evaluate accelerations at the current positions without integrating
+ * (Simulation::attract(), Simulation.hpp:176-214, as a direct sum). */
+int nb_accelerations(nb_sim *s);
+
+/* Total energy, fp64 accumulation on the device, softening-consistent with the
+ * force (Quadtree.hpp:140-142): K = sum m v^2/2, U = -sum_{i<j} m_i m_j/sqrt(r^2+eps^2).
+ * Replaces the unusable calculateMetrics (main.cpp:91-194) / Body::kinetic_energy
+ * (Body.hpp:98-101).  On a sharded handle K and U are the owned block's share
+ * (U_i counted as 1/2 sum_{j!=i}), so the shares of all ranks add up to the total. */
+int nb_energy(nb_sim *s, double *kinetic, double *potential);
+
+/* Counters: Simulation::frame (Simulation.hpp:53) and sizes. */
+uint64_t nb_frame(const nb_sim *s);
+size_t   nb_count(const nb_sim *s);        /* n of the whole system */
+size_t   nb_owned_begin(const nb_sim *s);
+size_t   nb_owned_count(const nb_sim *s);
+
+/* ---- dump / restore (build-defined: the reference has no file I/O) ----
+ * File = 64-byte header {"NBODYAMD", u32 version, u32 sizeof(nb_body), u64 n,
+ * u64 frame, f32 eps, f32 dt, i32 precision, i32 rsqrt_mode, zero pad} followed
+ * by n raw nb_body records (padding zeroed) — the reference's only externally
+ * visible state, `std::vector<Body>`. */
+int nb_dump(nb_sim *s, const char *path);
+/* Host-only halves of the same format (usable without a GPU). */
+int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t frame,
+                    const nb_params *params);
+int nb_read_header(const char *path, size_t *n, uint64_t *frame, nb_params *params);
+int nb_read_bodies(const char *path, nb_body *out, size_t n);
+
+/* ---- sharded stepping (one process per GPU) ----------------------
+ * A handle created with i_count < n integrates its block only and needs the
+ * other blocks' positions each step.  The exchange itself is the host's
+ * (torch.distributed / RCCL all-gather writing straight into the device
+ * position replica), overlapped with the local-tile force:
+ *
+ *   nb_step_begin(s, dt)   enqueue: force from the OWNED j-block (already resident)
+ *   ... host runs the all-gather into nb_pos_buffer(s, NB_POS_CURRENT) on its comm stream ...
+ *   nb_step_finish(s)      enqueue: force from the remote j-blocks, kick, drift;
+ *                          new owned positions land in the NEXT replica, which
+ *                          becomes CURRENT.
+ * Stream ordering between the two calls and the collective is the caller's
+ * (they share params.stream, or use events). */
+enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
+int   nb_step_begin(nb_sim *s, float dt);
+int   nb_step_finish(nb_sim *s);
+void *nb_pos_buffer(nb_sim *s, int which);   /* device pointer, n*(x,y) reals */
+void *nb_stream(nb_sim *s);                  /* hipStream_t in use */
+
+/* ---- measurement ------------------------------------------------------------ */
+/* When enabled, every force-kernel launch is bracketed by HIP events on the
+ * handle's stream; nb_profile_read returns the summed kernel time and launch
+ * count since the last reset (it synchronises). */
+int nb_profile_enable(nb_sim *s, int on);
+int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *force_launches, int reset);
+
+/* Describe the launch geometry chosen for the force kernel (for logs/DESIGN). */
+int nb_describe(nb_sim *s, char *buf, size_t buflen);
+
+/* ---- host utilities ----------------------------------------------------------- */
+/* Synthetic workload: 3-D Plummer sphere (a = M = G = 1,
+ * Aarseth-Henon-Wielen sampling, r <= 20) projected on (x,y),(vx,vy); equal
+ * masses 1/n, radius 0, acc 0.  mt19937(seed) raw outputs mapped (u+0.5)/2^32. */
+int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed);
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int nb_device_count(void);
+
+/* Text of the last error on this thread ("" if none). */
+const char *nb_last_error(void);
+
+/* NB_ABI_VERSION the library was built with. */
+int nb_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H */

@@ -1,0 +1,152 @@
+"""ctypes binding of ``libnbody_hip.so`` (the C ABI declared in ``include/nbody.h``).
+
+The binding is deliberately thin: it declares the structs and prototypes and
+fails loudly.  There is no Python or CPU fallback for any compute entry point —
+if the shared library is missing ``load()`` raises, and on a machine without a
+HIP device ``nb_create`` returns NULL (``NB_ENODEVICE``), which the wrappers
+turn into ``NBodyError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libnbody_hip.so"
+
+NB_ABI_VERSION = 1
+
+# enums (include/nbody.h)
+NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
+NB_FP32, NB_FP64 = 0, 1
+NB_RSQRT_EXACT, NB_RSQRT_QUAKE = 0, 1
+NB_SUM_TILED, NB_SUM_SEQUENTIAL = 0, 1
+NB_EXTRA_VCLAMP, NB_EXTRA_BOUNDARY = 1, 2
+NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
+NB_POS_CURRENT, NB_POS_NEXT = 0, 1
+
+#: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
+BODY_DTYPE = np.dtype(
+    {
+        "names": ["pos", "vel", "acc", "mass", "radius"],
+        "formats": [(np.float32, 2), (np.float32, 2), (np.float32, 2), np.float32, np.float32],
+        "offsets": [0, 16, 32, 48, 52],
+        "itemsize": 64,
+    }
+)
+
+
+class NBodyError(RuntimeError):
+    """Raised for every non-zero status / NULL handle coming out of the C ABI."""
+
+    def __init__(self, where: str, code: int, text: str):
+        super().__init__(f"{where}: [{code}] {text}")
+        self.code = code
+
+
+class nb_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("eps", C.c_float),
+        ("dt", C.c_float),
+        ("precision", C.c_int32),
+        ("rsqrt_mode", C.c_int32),
+        ("sum_order", C.c_int32),
+        ("integrator", C.c_int32),
+        ("extras", C.c_int32),
+        ("device", C.c_int32),
+        ("j_slices", C.c_int32),
+        ("i_begin", C.c_uint64),
+        ("i_count", C.c_uint64),
+        ("stream", C.c_void_p),
+        ("pos_buffers", C.c_void_p * 2),
+    ]
+
+
+#: every symbol include/nbody.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "nb_params_default": (None, [C.POINTER(nb_params)]),
+    "nb_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(nb_params)]),
+    "nb_destroy": (None, [C.c_void_p]),
+    "nb_step": (C.c_int, [C.c_void_p, C.c_float, C.c_int]),
+    "nb_wait": (C.c_int, [C.c_void_p]),
+    "nb_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nb_sync_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nb_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nb_accelerations": (C.c_int, [C.c_void_p]),
+    "nb_energy": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nb_frame": (C.c_uint64, [C.c_void_p]),
+    "nb_count": (C.c_size_t, [C.c_void_p]),
+    "nb_owned_begin": (C.c_size_t, [C.c_void_p]),
+    "nb_owned_count": (C.c_size_t, [C.c_void_p]),
+    "nb_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "nb_write_bodies": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(nb_params)]),
+    "nb_read_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(nb_params)]),
+    "nb_read_bodies": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "nb_step_begin": (C.c_int, [C.c_void_p, C.c_float]),
+    "nb_step_finish": (C.c_int, [C.c_void_p]),
+    "nb_pos_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "nb_stream": (C.c_void_p, [C.c_void_p]),
+    "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "nb_device_count": (C.c_int, []),
+    "nb_last_error": (C.c_char_p, []),
+    "nb_abi_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the product library; raise if it is missing or its ABI differs."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("NBODY_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nbodysim_amd/csrc` (there is no CPU fallback)"
+        )
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.nb_abi_version() != NB_ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.nb_abi_version()} != binding {NB_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().nb_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(where: str, rc: int) -> None:
+    if rc != NB_OK:
+        raise NBodyError(where, rc, last_error())
+
+
+def default_params() -> nb_params:
+    p = nb_params()
+    load().nb_params_default(C.byref(p))
+    return p
+
+
+def bodies_array(n: int) -> np.ndarray:
+    """Zero-initialised array of n 64-byte Body records (padding zero)."""
+    raw = np.zeros(n * BODY_DTYPE.itemsize, dtype=np.uint8)
+    return raw.view(BODY_DTYPE)
+
+
+def plummer_2d(n: int, seed: int = 42) -> np.ndarray:
+    """Synthetic workload of SURVEY §8d through the library's generator."""
+    out = bodies_array(n)
+    check("nb_plummer_2d", load().nb_plummer_2d(out.ctypes.data, n, seed))
+    return out

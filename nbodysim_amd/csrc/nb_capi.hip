@@ -1,0 +1,634 @@
+// nb_capi.hip — the C ABI of include/nbody.h over the gfx950 kernels.
+//
+// One nb_sim stands for one `Simulation` of the reference
+// (Nbodysim/headers/Simulation.hpp:49-75).  Device state is SoA:
+//   pos[2]   full-n (x,y) replicas, double buffered (step n reads cur, writes next)
+//   mass     full n            radius  full n (carried, float)
+//   vel,acc  owned block only  partial [slabs][i_count] force partial sums
+// No CPU fallback exists: every entry that computes needs a HIP device.
+#include "nbody.h"
+#include "nb_internal.h"
+#include "nb_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace nbk;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" void nb_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" void nb_clear_error(void) { g_err[0] = 0; }
+extern "C" const char *nb_last_error(void) { return g_err; }
+extern "C" int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+#define HIPCHK(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            nb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NB_EHIP;                                                           \
+        }                                                                             \
+    } while (0)
+
+extern "C" int nb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" void nb_params_default(nb_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->struct_size = (uint32_t)sizeof(nb_params);
+    p->eps = 1.0f;   // Simulation.hpp:59  quadtree(1.0f, 1.0f, 16)
+    p->dt = 0.01f;   // main.cpp:39        SIMULATION_DT{0.01f}
+    p->precision = NB_FP32;
+    p->rsqrt_mode = NB_RSQRT_EXACT;
+    p->sum_order = NB_SUM_TILED;
+    p->integrator = NB_INTEGRATOR_KICK_DRIFT;
+    p->extras = 0;
+    p->device = -1;
+    p->j_slices = 0;
+}
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+struct ForceJob { uint32_t j_begin, j_end, js, slab0; };
+
+struct nb_sim {
+    nb_params p;
+    size_t n = 0, i_begin = 0, i_count = 0;
+    int dev = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool fp64 = false;
+    size_t rsz = 4;            // sizeof(real)
+
+    void *pos[2] = {nullptr, nullptr};
+    bool own_pos = true;
+    int cur = 0;
+    void *mass = nullptr;
+    float *radius = nullptr;
+    void *vel = nullptr, *acc = nullptr;
+    void *partial = nullptr;
+    uint32_t slabs_cap = 0;
+    BodyRec *aos_dev = nullptr;     // n records (upload) / i_count records (sync)
+    void *staging = nullptr;        // pinned host, i_count * 64 B
+    double *ered_dev = nullptr;     // energy partials
+    size_t ered_blocks = 0;
+
+    // launch geometry
+    int P = 2;
+    ForceJob job_all{}, job_local{}, job_before{}, job_after{};
+    uint32_t slabs_all = 0, slabs_two_phase = 0;
+
+    uint64_t frame = 0;
+    float pending_dt = 0.f;
+    bool in_step = false;
+    bool acc_valid = false;         // KDK: acc holds a(x_cur)
+
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_used;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0;
+};
+
+static int bind(const nb_sim *s)
+{
+    int d = -1;
+    HIPCHK(hipGetDevice(&d));
+    if (d != s->dev) HIPCHK(hipSetDevice(s->dev));
+    return NB_OK;
+}
+
+// Choose j-slices so that the force grid has about 2 workgroups (8 waves) per CU.
+static uint32_t pick_slices(uint32_t i_tiles, uint32_t jn, int cus, int forced)
+{
+    uint32_t max_js = jn / TJ ? jn / TJ : 1;  // every slice gets at least one full tile
+    uint32_t js = 1;
+    if (forced > 0) js = (uint32_t)forced;
+    else {
+        const uint32_t target = 2u * (uint32_t)cus;
+        while (i_tiles * js < target && js < max_js) js = js < 8 ? js * 2 : js + 8;
+    }
+    if (js > max_js) js = max_js;
+    // legal values for decode_block: 1, 2, 4 or a multiple of 8
+    if (js >= 8) js = (js / 8) * 8;
+    else if (js == 3) js = 2;
+    else if (js >= 5) js = 4;
+    return js ? js : 1;
+}
+
+static void plan(nb_sim *s)
+{
+    const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
+    const uint32_t n = (uint32_t)s->n, ib = (uint32_t)s->i_begin, ic = (uint32_t)s->i_count;
+    // lanes own 2P particles (fp32) or P (fp64); fewer per lane when i is scarce
+    const char *envp = getenv("NB_FORCE_P");
+    if (s->fp64) s->P = ic >= (uint32_t)s->cus * BLOCK * 2 ? 2 : 1;
+    else s->P = ic >= (uint32_t)s->cus * BLOCK * 4 ? 2 : 1;
+    if (envp && (atoi(envp) == 1 || atoi(envp) == 2)) s->P = atoi(envp);
+    const uint32_t per_tile = s->fp64 ? BLOCK * s->P : BLOCK * 2 * s->P;
+    const uint32_t i_tiles = (ic + per_tile - 1) / per_tile;
+    auto mk = [&](uint32_t jb, uint32_t je, uint32_t slab0) {
+        ForceJob j{jb, je, 0, slab0};
+        if (je > jb) j.js = seq ? 1 : pick_slices(i_tiles, je - jb, s->cus, s->p.j_slices);
+        return j;
+    };
+    s->job_all = mk(0, n, 0);
+    s->slabs_all = s->job_all.js;
+    s->job_local = mk(ib, ib + ic, 0);
+    s->job_before = mk(0, ib, s->job_local.js);
+    s->job_after = mk(ib + ic, n, s->job_local.js + s->job_before.js);
+    s->slabs_two_phase = s->job_local.js + s->job_before.js + s->job_after.js;
+}
+
+static void free_all(nb_sim *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->dev);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : s->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (s->own_pos) { (void)hipFree(s->pos[0]); (void)hipFree(s->pos[1]); }
+    (void)hipFree(s->mass); (void)hipFree(s->radius);
+    (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
+    (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
+    if (s->staging) (void)hipHostFree(s->staging);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static int do_upload(nb_sim *s, const nb_body *in)
+{
+    HIPCHK(hipMemcpyAsync(s->aos_dev, in, s->n * sizeof(nb_body), hipMemcpyHostToDevice, s->stream));
+    const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
+    // both replicas get the full initial positions
+    for (int b = 0; b < 2; ++b) {
+        if (s->fp64)
+            unpack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (double2 *)s->pos[b], (double *)s->mass,
+                                                             (double2 *)s->vel, (double2 *)s->acc, s->radius,
+                                                             (uint32_t)s->i_begin, (uint32_t)s->i_count);
+        else
+            unpack_bodies<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (float2 *)s->pos[b], (float *)s->mass,
+                                                            (float2 *)s->vel, (float2 *)s->acc, s->radius,
+                                                            (uint32_t)s->i_begin, (uint32_t)s->i_count);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));  // `in` may be pageable and freed by the caller
+    s->acc_valid = false;
+    return NB_OK;
+}
+
+extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *params)
+{
+    nb_clear_error();
+    nb_params p;
+    if (params) {
+        if (params->struct_size != sizeof(nb_params)) {
+            nb_set_error("nb_create: params->struct_size %u != %zu (use nb_params_default)", params->struct_size, sizeof(nb_params));
+            return nullptr;
+        }
+        p = *params;
+    } else nb_params_default(&p);
+    if (!init || n == 0) { nb_set_error("nb_create: no bodies"); return nullptr; }
+    if (n > 0x7fffff00u) { nb_set_error("nb_create: n=%zu exceeds the 32-bit index range of the kernels", n); return nullptr; }
+    if (!(p.eps >= 0.0f)) { nb_set_error("nb_create: eps must be >= 0"); return nullptr; }
+    if (p.precision != NB_FP32 && p.precision != NB_FP64) { nb_set_error("nb_create: bad precision %d", p.precision); return nullptr; }
+    if (p.rsqrt_mode != NB_RSQRT_EXACT && p.rsqrt_mode != NB_RSQRT_QUAKE) { nb_set_error("nb_create: bad rsqrt_mode %d", p.rsqrt_mode); return nullptr; }
+    if (p.sum_order != NB_SUM_TILED && p.sum_order != NB_SUM_SEQUENTIAL) { nb_set_error("nb_create: bad sum_order %d", p.sum_order); return nullptr; }
+    if (p.integrator != NB_INTEGRATOR_KICK_DRIFT && p.integrator != NB_INTEGRATOR_KDK) { nb_set_error("nb_create: bad integrator %d", p.integrator); return nullptr; }
+    if (p.precision == NB_FP64 && (p.rsqrt_mode == NB_RSQRT_QUAKE || p.sum_order == NB_SUM_SEQUENTIAL)) {
+        nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
+        return nullptr;
+    }
+    if (p.i_count == 0) { p.i_begin = 0; p.i_count = n; }
+    if (p.i_begin + p.i_count > n) { nb_set_error("nb_create: owned block [%llu,+%llu) exceeds n=%zu", (unsigned long long)p.i_begin, (unsigned long long)p.i_count, n); return nullptr; }
+    if ((p.pos_buffers[0] == nullptr) != (p.pos_buffers[1] == nullptr)) { nb_set_error("nb_create: give both pos_buffers or none"); return nullptr; }
+
+    int ndev = nb_device_count();
+    if (ndev <= 0) { nb_set_error("nb_create: no HIP device visible (this library has no CPU path)"); return nullptr; }
+    int dev = p.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { nb_set_error("nb_create: device %d out of range (%d visible)", dev, ndev); return nullptr; }
+
+    nb_sim *s = new (std::nothrow) nb_sim;
+    if (!s) { nb_set_error("nb_create: out of host memory"); return nullptr; }
+    s->p = p; s->n = n; s->i_begin = (size_t)p.i_begin; s->i_count = (size_t)p.i_count; s->dev = dev;
+    s->fp64 = p.precision == NB_FP64;
+    s->rsz = s->fp64 ? 8 : 4;
+
+    auto fail = [&](const char *what, hipError_t e) -> nb_sim * {
+        nb_set_error("nb_create: %s: %s", what, hipGetErrorString(e));
+        free_all(s);
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(dev)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    s->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (p.stream) { s->stream = (hipStream_t)p.stream; s->own_stream = false; }
+    else { if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e); s->own_stream = true; }
+
+    plan(s);
+    const size_t r2 = 2 * s->rsz;
+    if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; }
+    else {
+        if ((e = hipMalloc(&s->pos[0], n * r2)) != hipSuccess) return fail("hipMalloc pos", e);
+        if ((e = hipMalloc(&s->pos[1], n * r2)) != hipSuccess) return fail("hipMalloc pos", e);
+    }
+    s->slabs_cap = s->slabs_all > s->slabs_two_phase ? s->slabs_all : s->slabs_two_phase;
+    if ((e = hipMalloc(&s->mass, n * s->rsz)) != hipSuccess) return fail("hipMalloc mass", e);
+    if ((e = hipMalloc((void **)&s->radius, n * sizeof(float))) != hipSuccess) return fail("hipMalloc radius", e);
+    if ((e = hipMalloc(&s->vel, s->i_count * r2)) != hipSuccess) return fail("hipMalloc vel", e);
+    if ((e = hipMalloc(&s->acc, s->i_count * r2)) != hipSuccess) return fail("hipMalloc acc", e);
+    if ((e = hipMalloc(&s->partial, (size_t)s->slabs_cap * s->i_count * r2)) != hipSuccess) return fail("hipMalloc partial", e);
+    if ((e = hipMalloc((void **)&s->aos_dev, n * sizeof(nb_body))) != hipSuccess) return fail("hipMalloc aos", e);
+    s->ered_blocks = (s->i_count + BLOCK - 1) / BLOCK;
+    if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
+
+    if (do_upload(s, init) != NB_OK) { free_all(s); return nullptr; }
+    return s;
+}
+
+extern "C" void nb_destroy(nb_sim *s) { free_all(s); }
+
+extern "C" int nb_upload(nb_sim *s, const nb_body *in)
+{
+    if (!s || !in) { nb_set_error("nb_upload: NULL argument"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    return do_upload(s, in);
+}
+
+// ---------------------------------------------------------------------------
+// profiling events
+// ---------------------------------------------------------------------------
+static int prof_begin(nb_sim *s, std::pair<hipEvent_t, hipEvent_t> *pr)
+{
+    if (s->ev_pool.empty()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        s->ev_pool.push_back({a, b});
+    }
+    *pr = s->ev_pool.back();
+    s->ev_pool.pop_back();
+    HIPCHK(hipEventRecord(pr->first, s->stream));
+    return NB_OK;
+}
+
+static int prof_end(nb_sim *s, const std::pair<hipEvent_t, hipEvent_t> &pr)
+{
+    HIPCHK(hipEventRecord(pr.second, s->stream));
+    s->ev_used.push_back(pr);
+    return NB_OK;
+}
+
+static int prof_collect(nb_sim *s)
+{
+    for (auto &pr : s->ev_used) {
+        HIPCHK(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        s->prof_ms += ms;
+        s->prof_launches += 1;
+        s->ev_pool.push_back(pr);
+    }
+    s->ev_used.clear();
+    return NB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// force launch
+// ---------------------------------------------------------------------------
+template <int P, int RSQ, bool GUARD>
+static void launch_tiled_f32(nb_sim *s, const ForceJob &j, uint32_t i_tiles, float eps2)
+{
+    const uint32_t grid = grid_blocks(i_tiles, j.js);
+    float2 *out = (float2 *)s->partial + (size_t)j.slab0 * s->i_count;
+    force_tiled_f32<P, RSQ, GUARD, 8><<<grid, BLOCK, 0, s->stream>>>(
+        (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2);
+}
+
+template <int P, bool GUARD>
+static void launch_tiled_f64(nb_sim *s, const ForceJob &j, uint32_t i_tiles, double eps2)
+{
+    const uint32_t grid = grid_blocks(i_tiles, j.js);
+    double2 *out = (double2 *)s->partial + (size_t)j.slab0 * s->i_count;
+    force_tiled_f64<P, GUARD, 4><<<grid, BLOCK, 0, s->stream>>>(
+        (const double2 *)s->pos[s->cur], (const double *)s->mass, out,
+        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2);
+}
+
+static int launch_force(nb_sim *s, const ForceJob &j)
+{
+    if (j.j_end <= j.j_begin || j.js == 0) return NB_OK;
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+    const bool guard = s->p.eps == 0.0f;
+    const uint32_t ic = (uint32_t)s->i_count;
+    if (s->fp64) {
+        const double eps2 = (double)s->p.eps * (double)s->p.eps;
+        const uint32_t i_tiles = (ic + BLOCK * s->P - 1) / (BLOCK * s->P);
+        if (s->P == 2) { if (guard) launch_tiled_f64<2, true>(s, j, i_tiles, eps2); else launch_tiled_f64<2, false>(s, j, i_tiles, eps2); }
+        else           { if (guard) launch_tiled_f64<1, true>(s, j, i_tiles, eps2); else launch_tiled_f64<1, false>(s, j, i_tiles, eps2); }
+    } else {
+        const float eps2 = s->p.eps * s->p.eps;   // Quadtree.hpp:19  e_sq(epsilon * epsilon)
+        if (s->p.sum_order == NB_SUM_SEQUENTIAL) {
+            const uint32_t grid = (ic + BLOCK - 1) / BLOCK;
+            float2 *out = (float2 *)s->partial + (size_t)j.slab0 * s->i_count;
+            if (s->p.rsqrt_mode == NB_RSQRT_QUAKE)
+                force_seq_f32<RSQ_QUAKE><<<grid, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+                                                                          (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, eps2);
+            else
+                force_seq_f32<RSQ_EXACT><<<grid, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+                                                                          (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, eps2);
+        } else {
+            const uint32_t i_tiles = (ic + BLOCK * 2 * s->P - 1) / (BLOCK * 2 * s->P);
+            const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
+#define NB_DISPATCH(PP)                                                                           \
+            do {                                                                                  \
+                if (quake) { if (guard) launch_tiled_f32<PP, RSQ_QUAKE, true>(s, j, i_tiles, eps2);  \
+                             else       launch_tiled_f32<PP, RSQ_QUAKE, false>(s, j, i_tiles, eps2); } \
+                else       { if (guard) launch_tiled_f32<PP, RSQ_EXACT, true>(s, j, i_tiles, eps2);  \
+                             else       launch_tiled_f32<PP, RSQ_EXACT, false>(s, j, i_tiles, eps2); } \
+            } while (0)
+            if (s->P == 2) NB_DISPATCH(2); else NB_DISPATCH(1);
+#undef NB_DISPATCH
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if (s->prof && prof_end(s, pr)) return NB_EHIP;
+    return NB_OK;
+}
+
+static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double dt_drift, int flags)
+{
+    const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+    const bool strict = s->p.sum_order == NB_SUM_SEQUENTIAL;
+    const int nxt = s->cur ^ 1;
+    if (s->fp64)
+        integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
+                                                             (double2 *)s->acc, (const double2 *)s->partial, nslabs,
+                                                             (uint32_t)s->i_begin, ic, dt_kick, dt_drift, s->p.extras, flags);
+    else if (strict)
+        integrate<float, true><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
+                                                           (float2 *)s->acc, (const float2 *)s->partial, nslabs,
+                                                           (uint32_t)s->i_begin, ic, (float)dt_kick, (float)dt_drift, s->p.extras, flags);
+    else
+        integrate<float, false><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
+                                                            (float2 *)s->acc, (const float2 *)s->partial, nslabs,
+                                                            (uint32_t)s->i_begin, ic, (float)dt_kick, (float)dt_drift, s->p.extras, flags);
+    HIPCHK(hipGetLastError());
+    return NB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stepping
+// ---------------------------------------------------------------------------
+static bool sharded(const nb_sim *s) { return s->i_count != s->n; }
+static bool two_phase(const nb_sim *s) { return sharded(s) && s->p.sum_order != NB_SUM_SEQUENTIAL; }
+
+extern "C" int nb_step_begin(nb_sim *s, float dt)
+{
+    if (!s) { nb_set_error("nb_step_begin: NULL handle"); return NB_EINVAL; }
+    if (s->in_step) { nb_set_error("nb_step_begin: previous step not finished"); return NB_ESTATE; }
+    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) { nb_set_error("sharded stepping supports the kick-drift integrator only"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    s->pending_dt = dt > 0.0f ? dt : s->p.dt;
+    s->in_step = true;
+    // local j-block first: its positions are already resident, so this overlaps the exchange
+    if (two_phase(s)) return launch_force(s, s->job_local);
+    return NB_OK;
+}
+
+extern "C" int nb_step_finish(nb_sim *s)
+{
+    if (!s) { nb_set_error("nb_step_finish: NULL handle"); return NB_EINVAL; }
+    if (!s->in_step) { nb_set_error("nb_step_finish: no step in flight"); return NB_ESTATE; }
+    if (bind(s)) return NB_EHIP;
+    s->in_step = false;
+    int rc;
+    uint32_t nslabs;
+    if (two_phase(s)) {
+        if ((rc = launch_force(s, s->job_before))) return rc;
+        if ((rc = launch_force(s, s->job_after))) return rc;
+        nslabs = s->slabs_two_phase;
+    } else {
+        if ((rc = launch_force(s, s->job_all))) return rc;
+        nslabs = s->slabs_all;
+    }
+    const double dt = s->pending_dt;
+    if ((rc = launch_integrate(s, nslabs, dt, dt, INTEG_KICK | INTEG_DRIFT))) return rc;
+    s->cur ^= 1;
+    s->frame += 1;                                  // Simulation.hpp:74
+    s->acc_valid = false;
+    return NB_OK;
+}
+
+static int step_kdk(nb_sim *s, double dt)
+{
+    int rc;
+    if (!s->acc_valid) {                            // a(x_n), first step only
+        if ((rc = launch_force(s, s->job_all))) return rc;
+        if ((rc = launch_integrate(s, s->slabs_all, 0.0, 0.0, 0))) return rc;   // acc <- slabs only
+    } else {
+        // acc already holds a(x_n): re-present it as the single slab 0
+        HIPCHK(hipMemcpyAsync(s->partial, s->acc, s->i_count * 2 * s->rsz, hipMemcpyDeviceToDevice, s->stream));
+    }
+    // half kick + drift (acc from slab(s)), then force at x_{n+1} and the second half kick
+    if ((rc = launch_integrate(s, s->acc_valid ? 1 : s->slabs_all, 0.5 * dt, dt, INTEG_KICK | INTEG_DRIFT))) return rc;
+    s->cur ^= 1;
+    if ((rc = launch_force(s, s->job_all))) return rc;
+    if ((rc = launch_integrate(s, s->slabs_all, 0.5 * dt, 0.0, INTEG_KICK))) return rc;
+    s->acc_valid = true;
+    s->frame += 1;
+    return NB_OK;
+}
+
+extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
+{
+    if (!s) { nb_set_error("nb_step: NULL handle"); return NB_EINVAL; }
+    if (nsteps < 0) { nb_set_error("nb_step: nsteps < 0"); return NB_EINVAL; }
+    if (sharded(s)) { nb_set_error("nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish"); return NB_ESTATE; }
+    if (s->in_step) { nb_set_error("nb_step: a split step is in flight"); return NB_ESTATE; }
+    if (bind(s)) return NB_EHIP;
+    const float h = dt > 0.0f ? dt : s->p.dt;
+    for (int k = 0; k < nsteps; ++k) {
+        int rc;
+        if (s->p.integrator == NB_INTEGRATOR_KDK) { if ((rc = step_kdk(s, h))) return rc; continue; }
+        if ((rc = nb_step_begin(s, h))) return rc;
+        if ((rc = nb_step_finish(s))) return rc;
+        // keep the event list bounded on long runs
+        if (s->prof && s->ev_used.size() >= 2048 && (rc = prof_collect(s))) return rc;
+    }
+    return NB_OK;
+}
+
+extern "C" int nb_accelerations(nb_sim *s)
+{
+    if (!s) { nb_set_error("nb_accelerations: NULL handle"); return NB_EINVAL; }
+    if (s->in_step) { nb_set_error("nb_accelerations: a split step is in flight"); return NB_ESTATE; }
+    if (bind(s)) return NB_EHIP;
+    int rc;
+    if ((rc = launch_force(s, s->job_all))) return rc;
+    return launch_integrate(s, s->slabs_all, 0.0, 0.0, 0);   // acc <- sum of slabs, nothing else
+}
+
+extern "C" int nb_wait(nb_sim *s)
+{
+    if (!s) { nb_set_error("nb_wait: NULL handle"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host views
+// ---------------------------------------------------------------------------
+static int ensure_staging(nb_sim *s)
+{
+    if (!s->staging) HIPCHK(hipHostMalloc(&s->staging, s->i_count * sizeof(nb_body), hipHostMallocDefault));
+    return NB_OK;
+}
+
+extern "C" int nb_sync(nb_sim *s, nb_body *out)
+{
+    if (!s || !out) { nb_set_error("nb_sync: NULL argument"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    if (ensure_staging(s)) return NB_EHIP;
+    const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+    if (s->fp64)
+        pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double2 *)s->pos[s->cur], (const double *)s->mass,
+                                                        (const double2 *)s->vel, (const double2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
+    else
+        pack_bodies<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float2 *)s->pos[s->cur], (const float *)s->mass,
+                                                       (const float2 *)s->vel, (const float2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    memcpy(out, s->staging, s->i_count * sizeof(nb_body));
+    return NB_OK;
+}
+
+extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
+{
+    if (!s || !out_xy) { nb_set_error("nb_sync_positions: NULL argument"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    if (ensure_staging(s)) return NB_EHIP;
+    const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+    if (s->fp64) {
+        pack_positions<double><<<g, BLOCK, 0, s->stream>>>((float2 *)s->aos_dev, (const double2 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, s->i_count * sizeof(float2), hipMemcpyDeviceToHost, s->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(s->staging, (const float2 *)s->pos[s->cur] + s->i_begin, s->i_count * sizeof(float2),
+                              hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    memcpy(out_xy, s->staging, s->i_count * sizeof(float2));
+    return NB_OK;
+}
+
+extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
+{
+    if (!s || !kinetic || !potential) { nb_set_error("nb_energy: NULL argument"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    const uint32_t g = (uint32_t)s->ered_blocks;
+    const double eps2 = (double)s->p.eps * (double)s->p.eps;
+    if (s->fp64)
+        energy_partials<double><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (const double *)s->mass, (const double2 *)s->vel,
+                                                            (uint32_t)s->n, (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2,
+                                                            s->ered_dev, s->ered_dev + g);
+    else
+        energy_partials<float><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (const float *)s->mass, (const float2 *)s->vel,
+                                                           (uint32_t)s->n, (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2,
+                                                           s->ered_dev, s->ered_dev + g);
+    HIPCHK(hipGetLastError());
+    std::vector<double> h(2 * (size_t)g);
+    HIPCHK(hipMemcpyAsync(h.data(), s->ered_dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double K = 0.0, U = 0.0;
+    for (uint32_t b = 0; b < g; ++b) { K += h[b]; U += h[g + b]; }
+    *kinetic = K;
+    *potential = U;
+    return NB_OK;
+}
+
+extern "C" uint64_t nb_frame(const nb_sim *s) { return s ? s->frame : 0; }
+extern "C" size_t nb_count(const nb_sim *s) { return s ? s->n : 0; }
+extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
+extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
+extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
+extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+
+extern "C" int nb_dump(nb_sim *s, const char *path)
+{
+    if (!s || !path) { nb_set_error("nb_dump: NULL argument"); return NB_EINVAL; }
+    if (sharded(s)) { nb_set_error("nb_dump: sharded handle holds only its block; gather on the host and use nb_write_bodies"); return NB_ESTATE; }
+    std::vector<nb_body> host(s->n);
+    int rc = nb_sync(s, host.data());
+    if (rc) return rc;
+    return nb_write_bodies(path, host.data(), s->n, s->frame, &s->p);
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int nb_profile_enable(nb_sim *s, int on)
+{
+    if (!s) { nb_set_error("nb_profile_enable: NULL handle"); return NB_EINVAL; }
+    s->prof = on != 0;
+    return NB_OK;
+}
+
+extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *force_launches, int reset)
+{
+    if (!s) { nb_set_error("nb_profile_read: NULL handle"); return NB_EINVAL; }
+    if (bind(s)) return NB_EHIP;
+    int rc = prof_collect(s);
+    if (rc) return rc;
+    if (force_ms_total) *force_ms_total = s->prof_ms;
+    if (force_launches) *force_launches = s->prof_launches;
+    if (reset) { s->prof_ms = 0.0; s->prof_launches = 0; }
+    return NB_OK;
+}
+
+extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
+{
+    if (!s || !buf || !buflen) { nb_set_error("nb_describe: NULL argument"); return NB_EINVAL; }
+    const uint32_t per_tile = s->fp64 ? BLOCK * s->P : BLOCK * 2 * s->P;
+    const uint32_t i_tiles = ((uint32_t)s->i_count + per_tile - 1) / per_tile;
+    snprintf(buf, buflen,
+             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | two-phase slabs local/before/after=%u/%u/%u | CUs=%d",
+             s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
+             s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact",
+             s->p.sum_order == NB_SUM_SEQUENTIAL ? "sequential" : "tiled",
+             BLOCK, s->fp64 ? s->P : 2 * s->P, i_tiles, s->job_all.js,
+             s->p.sum_order == NB_SUM_SEQUENTIAL ? ((uint32_t)s->i_count + BLOCK - 1) / BLOCK : grid_blocks(i_tiles, s->job_all.js),
+             TJ, s->job_local.js, s->job_before.js, s->job_after.js, s->cus);
+    return NB_OK;
+}

@@ -1,0 +1,194 @@
+/* nb_host.c — host-only pieces of libnbody_hip.so (plain C, no HIP):
+ * synthetic initial conditions and the build-defined dump format.
+ *
+ * The reference has neither a Plummer generator (its ICs are
+ * Simulation::uniform_disc, Simulation.hpp:347-603, a Lorenz-attractor trace)
+ * nor any file I/O; both are defined here and documented in
+ * DESIGN.md as build-defined.
+ */
+#include "nbody.h"
+#include "nb_internal.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- mt19937 (Matsumoto & Nishimura 1998), same stream as std::mt19937(seed),
+ * which is the PRNG the reference seeds its ICs with (Simulation.hpp:349) ---- */
+typedef struct { uint32_t mt[624]; int idx; } nb_mt;
+
+static void mt_seed(nb_mt *g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+
+static uint32_t mt_next(nb_mt *g)
+{
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* portable uniform in (0,1): raw 32-bit output mapped (u + 0.5) / 2^32 in double */
+static double mt_u01(nb_mt *g) { return ((double)mt_next(g) + 0.5) * (1.0 / 4294967296.0); }
+
+/* 3-D Plummer model, Aarseth, Henon & Wielen (1974) sampling, a = M = G = 1,
+ * truncated at r <= 20, projected on the (x,y) plane. */
+int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed)
+{
+    if (!out && n) { nb_set_error("nb_plummer_2d: out is NULL"); return NB_EINVAL; }
+    nb_mt g;
+    mt_seed(&g, seed);
+    const double two_pi = 6.283185307179586476925286766559;
+    const float mass = n ? (float)(1.0 / (double)n) : 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        double r;
+        do {
+            double x1 = mt_u01(&g);
+            r = 1.0 / sqrt(pow(x1, -2.0 / 3.0) - 1.0);
+        } while (!(r <= 20.0));
+        double x2 = mt_u01(&g), x3 = mt_u01(&g);
+        double z = (1.0 - 2.0 * x2) * r;
+        double rho = sqrt(fmax(r * r - z * z, 0.0));
+        double px = rho * cos(two_pi * x3), py = rho * sin(two_pi * x3);
+
+        double q, gq;
+        do { /* von Neumann rejection on g(q) = q^2 (1-q^2)^(7/2), max < 0.1 */
+            q = mt_u01(&g);
+            gq = 0.1 * mt_u01(&g);
+        } while (gq > q * q * pow(1.0 - q * q, 3.5));
+        double v = q * sqrt(2.0) * pow(1.0 + r * r, -0.25);
+        double x6 = mt_u01(&g), x7 = mt_u01(&g);
+        double w = (1.0 - 2.0 * x6) * v;
+        double vr = sqrt(fmax(v * v - w * w, 0.0));
+        double vx = vr * cos(two_pi * x7), vy = vr * sin(two_pi * x7);
+
+        memset(&out[i], 0, sizeof(nb_body));
+        out[i].pos.x = (float)px; out[i].pos.y = (float)py;
+        out[i].vel.x = (float)vx; out[i].vel.y = (float)vy;
+        out[i].mass = mass;
+        out[i].radius = 0.0f;
+    }
+    return NB_OK;
+}
+
+/* ---- dump format ------------------------------------------------------------ */
+typedef struct nb_file_header {
+    char     magic[8];      /* "NBODYAMD" */
+    uint32_t version;       /* 1 */
+    uint32_t body_size;     /* 64 */
+    uint64_t n;
+    uint64_t frame;
+    float    eps;
+    float    dt;
+    int32_t  precision;
+    int32_t  rsqrt_mode;
+    uint8_t  pad[16];
+} nb_file_header;
+
+_Static_assert(sizeof(nb_file_header) == 64, "dump header is 64 bytes");
+
+int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t frame,
+                    const nb_params *params)
+{
+    if (!path || (!bodies && n)) { nb_set_error("nb_write_bodies: NULL argument"); return NB_EINVAL; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { nb_set_error("nb_write_bodies: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    nb_file_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "NBODYAMD", 8);
+    h.version = 1;
+    h.body_size = (uint32_t)sizeof(nb_body);
+    h.n = (uint64_t)n;
+    h.frame = frame;
+    if (params) {
+        h.eps = params->eps; h.dt = params->dt;
+        h.precision = params->precision; h.rsqrt_mode = params->rsqrt_mode;
+    }
+    int rc = NB_OK;
+    if (fwrite(&h, sizeof h, 1, f) != 1) rc = NB_EIO;
+    /* records are written with padding forced to zero, whatever the caller holds */
+    enum { CHUNK = 4096 };
+    nb_body *buf = (nb_body *)malloc(sizeof(nb_body) * CHUNK);
+    if (!buf) { fclose(f); nb_set_error("nb_write_bodies: out of memory"); return NB_ENOMEM; }
+    for (size_t base = 0; rc == NB_OK && base < n; base += CHUNK) {
+        size_t c = n - base < CHUNK ? n - base : CHUNK;
+        memset(buf, 0, sizeof(nb_body) * c);
+        for (size_t k = 0; k < c; ++k) {
+            const nb_body *b = &bodies[base + k];
+            buf[k].pos.x = b->pos.x; buf[k].pos.y = b->pos.y;
+            buf[k].vel.x = b->vel.x; buf[k].vel.y = b->vel.y;
+            buf[k].acc.x = b->acc.x; buf[k].acc.y = b->acc.y;
+            buf[k].mass = b->mass;   buf[k].radius = b->radius;
+        }
+        if (fwrite(buf, sizeof(nb_body), c, f) != c) rc = NB_EIO;
+    }
+    free(buf);
+    if (fclose(f) != 0) rc = NB_EIO;
+    if (rc != NB_OK) nb_set_error("nb_write_bodies: short write to %s", path);
+    return rc;
+}
+
+static int read_header(FILE *f, const char *path, nb_file_header *h)
+{
+    if (fread(h, sizeof *h, 1, f) != 1) { nb_set_error("%s: truncated header", path); return NB_EFORMAT; }
+    if (memcmp(h->magic, "NBODYAMD", 8) != 0) { nb_set_error("%s: bad magic", path); return NB_EFORMAT; }
+    if (h->version != 1 || h->body_size != sizeof(nb_body)) {
+        nb_set_error("%s: unsupported version %u / record size %u", path, h->version, h->body_size);
+        return NB_EFORMAT;
+    }
+    return NB_OK;
+}
+
+int nb_read_header(const char *path, size_t *n, uint64_t *frame, nb_params *params)
+{
+    if (!path) { nb_set_error("nb_read_header: NULL path"); return NB_EINVAL; }
+    FILE *f = fopen(path, "rb");
+    if (!f) { nb_set_error("nb_read_header: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    nb_file_header h;
+    int rc = read_header(f, path, &h);
+    fclose(f);
+    if (rc != NB_OK) return rc;
+    if (n) *n = (size_t)h.n;
+    if (frame) *frame = h.frame;
+    if (params) {
+        nb_params_default(params);
+        params->eps = h.eps; params->dt = h.dt;
+        params->precision = h.precision; params->rsqrt_mode = h.rsqrt_mode;
+    }
+    return NB_OK;
+}
+
+int nb_read_bodies(const char *path, nb_body *out, size_t n)
+{
+    if (!path || (!out && n)) { nb_set_error("nb_read_bodies: NULL argument"); return NB_EINVAL; }
+    FILE *f = fopen(path, "rb");
+    if (!f) { nb_set_error("nb_read_bodies: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    nb_file_header h;
+    int rc = read_header(f, path, &h);
+    if (rc == NB_OK && (size_t)h.n != n) {
+        nb_set_error("%s: holds %llu bodies, caller asked for %zu", path, (unsigned long long)h.n, n);
+        rc = NB_EINVAL;
+    }
+    if (rc == NB_OK && fread(out, sizeof(nb_body), n, f) != n) {
+        nb_set_error("%s: truncated body records", path);
+        rc = NB_EFORMAT;
+    }
+    fclose(f);
+    return rc;
+}

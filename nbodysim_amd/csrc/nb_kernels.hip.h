@@ -1,0 +1,542 @@
+// nb_kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
+//
+// Path replaced (reference, relative to Nbodysim/headers):
+//   Simulation::attract()  Simulation.hpp:176-214  -> force_* kernels (direct O(N^2))
+//   Quadtree::acc leaf loop Quadtree.hpp:134-144    -> the pair body
+//   Quadtree::fast_inv_sqrt Quadtree.hpp:106-111    -> quake_rsqrt / RSQ_QUAKE
+//   Simulation::iterate()  Simulation.hpp:129-163   -> integrate_* kernels
+//
+// Design: the pair body is pure fp32 VALU work
+// (9 packed ops + 2 v_rsq_f32 per TWO pairs); there is no contraction to feed
+// MFMA.  Each lane owns 2*P i-particles held as P packed register pairs
+// (v_pk_add/fma/mul_f32 process the two halves at once, the j-particle is
+// broadcast through op_sel), j-particles stream through a double-buffered LDS
+// tile as float4 {x, y, m, m} read back by one broadcast ds_read_b128 per j per
+// wave.  The j range can be split into slices across workgroups (grid-level
+// j-split) so that small i-counts still fill 256 CUs; slices write partial sums
+// to slabs that the integrate kernel adds in a fixed order (deterministic, no
+// atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbk {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int BLOCK = 256;  // 4 wave64 per workgroup
+constexpr int TJ = 256;     // j-particles per LDS tile (one per thread per stage)
+
+enum { RSQ_EXACT = 0, RSQ_QUAKE = 1 };
+
+// ---------------------------------------------------------------------------
+// Block -> (i_tile, j_slice) decode.  Workgroups are dealt round-robin over the
+// 8 XCDs (b % 8 shares an XCD, MI355X_MICROARCH §Workgroup dispatch): slices
+// are keyed on b % 8 so that all workgroups streaming the same j-slice sit on
+// one XCD and share its 4 MiB L2.  Speed only; any placement is correct.
+// ---------------------------------------------------------------------------
+struct TileMap { uint32_t i_tile, slice; bool valid; };
+
+__device__ __forceinline__ TileMap decode_block(uint32_t b, uint32_t i_tiles, uint32_t js)
+{
+    TileMap m;
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    if (js >= 8u) {                 // js is a multiple of 8 (host guarantees)
+        const uint32_t g = js >> 3;
+        m.slice = xcd + 8u * (k % g);
+        m.i_tile = k / g;
+    } else {                        // js in {1,2,4}
+        const uint32_t per = 8u / js;
+        m.slice = xcd % js;
+        m.i_tile = k * per + xcd / js;
+    }
+    m.valid = m.i_tile < i_tiles;
+    return m;
+}
+
+// grid size matching decode_block
+static inline uint32_t grid_blocks(uint32_t i_tiles, uint32_t js)
+{
+    if (js >= 8u) return i_tiles * js;
+    const uint32_t per = 8u / js;
+    return ((i_tiles + per - 1) / per) * 8u;
+}
+
+// Quadtree.hpp:106-111, operation order kept, no FMA contraction.
+__device__ __forceinline__ float quake_rsqrt(float number)
+{
+#pragma clang fp contract(off)
+    const float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(number) >> 1));
+    return y * (1.5f - (number * 0.5f * y * y));
+}
+
+__device__ __forceinline__ v2f quake_rsqrt2(v2f t)
+{
+#pragma clang fp contract(off)
+    v2f y = {__uint_as_float(0x5f3759dfu - (__float_as_uint(t.x) >> 1)),
+             __uint_as_float(0x5f3759dfu - (__float_as_uint(t.y) >> 1))};
+    const v2f half = {0.5f, 0.5f}, c15 = {1.5f, 1.5f};
+    return y * (c15 - (t * half * y * y));
+}
+
+// ---------------------------------------------------------------------------
+// force_tiled_f32 — the fast path.
+//   pos      (x,y) interleaved, full-n replica of the positions at t_n
+//   mass     full n
+//   partial  [js][i_count] partial accelerations of this launch's slabs
+//   i_begin/i_count   the owned block (particles this GPU integrates)
+//   j_begin/j_end     the j range of this launch, cut into js slices
+// Lane t of tile T owns particles  i_begin + T*IT + p*512 + 2t + {0,1},  p < P.
+// ---------------------------------------------------------------------------
+template <int P, int RSQ, bool GUARD, int UNROLL>
+__global__ __launch_bounds__(BLOCK)
+void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                     float2 *__restrict__ partial,
+                     uint32_t i_begin, uint32_t i_count,
+                     uint32_t j_begin, uint32_t j_end,
+                     uint32_t js, uint32_t i_tiles, float eps2)
+{
+    constexpr uint32_t IT = BLOCK * 2 * P;
+    __shared__ v4f tile[2][TJ];
+
+    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
+    if (!tm.valid) return;
+    const uint32_t t = threadIdx.x;
+
+    // slice bounds, multiples of TJ from j_begin
+    const uint32_t jn = j_end - j_begin;
+    const uint32_t slice_len = (((jn + js - 1) / js + TJ - 1) / TJ) * TJ;
+    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
+    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
+
+    // i-particles of this lane
+    v2f xi[P], yi[P], ax[P], ay[P];
+    uint32_t li[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        li[p] = tm.i_tile * IT + (uint32_t)p * (BLOCK * 2) + 2u * t;
+        const uint32_t l0 = min(li[p], i_count - 1), l1 = min(li[p] + 1, i_count - 1);
+        const float2 p0 = pos[i_begin + l0], p1 = pos[i_begin + l1];
+        xi[p] = (v2f){p0.x, p1.x};
+        yi[p] = (v2f){p0.y, p1.y};
+        ax[p] = (v2f){0.f, 0.f};
+        ay[p] = (v2f){0.f, 0.f};
+    }
+    const v2f e2 = {eps2, eps2};
+
+    const uint32_t ntiles = (s1 - s0 + TJ - 1) / TJ;
+    // stage tile 0
+    {
+        const uint32_t j = s0 + t;
+        float2 pj = make_float2(0.f, 0.f);
+        float mj = 0.f;
+        if (j < s1) { pj = pos[j]; mj = mass[j]; }
+        tile[0][t] = (v4f){pj.x, pj.y, mj, mj};
+    }
+    __syncthreads();
+
+    for (uint32_t it = 0; it < ntiles; ++it) {
+        // prefetch the next tile into registers while this one is consumed
+        float2 pn = make_float2(0.f, 0.f);
+        float mn = 0.f;
+        const uint32_t jn1 = s0 + (it + 1) * TJ + t;
+        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }
+
+        const v4f *__restrict__ cur = tile[it & 1];
+#pragma unroll UNROLL
+        for (int jj = 0; jj < TJ; ++jj) {
+            const v4f q = cur[jj];                 // broadcast ds_read_b128
+            const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, mj = {q.z, q.w};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const v2f dx = xj - xi[p];         // v_pk_add_f32 (neg)
+                const v2f dy = yj - yi[p];
+                v2f r2, inv;
+                if constexpr (GUARD) {
+                    // eps == 0: keep the reference's `if (r_sq > 0)` (Quadtree.hpp:139)
+                    r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+                    if constexpr (RSQ == RSQ_EXACT)
+                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else
+                        inv = quake_rsqrt2(r2);
+                    inv.x = r2.x > 0.f ? inv.x : 0.f;
+                    inv.y = r2.y > 0.f ? inv.y : 0.f;
+                } else {
+                    r2 = __builtin_elementwise_fma(dx, dx, e2);
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    if constexpr (RSQ == RSQ_EXACT)
+                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else
+                        inv = quake_rsqrt2(r2);
+                }
+                const v2f inv2 = inv * inv;
+                const v2f s = (mj * inv) * inv2;   // m / r^3
+                ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
+                ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
+            }
+        }
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = (v4f){pn.x, pn.y, mn, mn};
+        __syncthreads();
+    }
+
+    float2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (li[p] + 1 < i_count) {
+            *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+        } else if (li[p] < i_count) {
+            out[li[p]] = make_float2(ax[p].x, ay[p].x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force_seq_f32 — reference summation order (NB_SUM_SEQUENTIAL).
+// One lane per i, j ascending over the WHOLE range in one running sum, every
+// operation individually rounded (no FMA), guard `r_sq > 0` kept: the exact
+// arithmetic of Quadtree.hpp:134-144.  With RSQ_QUAKE the result is
+// bit-identical to the compiled reference (tests/test_parity_gpu.py).
+// ---------------------------------------------------------------------------
+template <int RSQ>
+__global__ __launch_bounds__(BLOCK)
+void force_seq_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                   float2 *__restrict__ partial,
+                   uint32_t i_begin, uint32_t i_count,
+                   uint32_t j_begin, uint32_t j_end, float eps2)
+{
+#pragma clang fp contract(off)
+    __shared__ v4f tile[2][TJ];
+    const uint32_t t = threadIdx.x;
+    const uint32_t li = blockIdx.x * BLOCK + t;
+    const float2 pi = pos[i_begin + min(li, i_count - 1)];
+    float sx = 0.f, sy = 0.f;
+
+    const uint32_t ntiles = (j_end - j_begin + TJ - 1) / TJ;
+    {
+        const uint32_t j = j_begin + t;
+        float2 pj = make_float2(0.f, 0.f); float mj = 0.f;
+        if (j < j_end) { pj = pos[j]; mj = mass[j]; }
+        tile[0][t] = (v4f){pj.x, pj.y, mj, 0.f};
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < ntiles; ++it) {
+        float2 pn = make_float2(0.f, 0.f); float mn = 0.f;
+        const uint32_t jn1 = j_begin + (it + 1) * TJ + t;
+        if (jn1 < j_end) { pn = pos[jn1]; mn = mass[jn1]; }
+        const v4f *__restrict__ cur = tile[it & 1];
+        const uint32_t cnt = min((uint32_t)TJ, j_end - (j_begin + it * TJ));
+        for (uint32_t jj = 0; jj < cnt; ++jj) {
+            const v4f q = cur[jj];
+            const float rx = q.x - pi.x;
+            const float ry = q.y - pi.y;
+            const float r_sq = rx * rx + ry * ry;
+            const float tt = r_sq + eps2;
+            float inv;
+            if constexpr (RSQ == RSQ_QUAKE) inv = quake_rsqrt(tt);
+            else inv = 1.0f / __fsqrt_rn(tt);
+            const float inv3 = inv * inv * inv;
+            const float s = q.z * inv3;
+            const float cx = rx * s, cy = ry * s;
+            sx = r_sq > 0.f ? sx + cx : sx;
+            sy = r_sq > 0.f ? sy + cy : sy;
+        }
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = (v4f){pn.x, pn.y, mn, 0.f};
+        __syncthreads();
+    }
+    if (li < i_count) partial[li] = make_float2(sx, sy);
+}
+
+// ---------------------------------------------------------------------------
+// force_tiled_f64 — fp64 extension (BASELINE config 5).  One i per lane per
+// register slot (P slots), same tiling; 1/sqrt from v_rsq_f64 refined by one
+// third-order step (relative error ~1e-16 after refinement).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_f64(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);            // v_rsq_f64, ~2^-26 relative
+    const double e = __builtin_fma(-x * y, y, 1.0);  // 1 - x y^2
+    // y * (1 + e/2 + 3e^2/8): third-order correction
+    const double c = __builtin_fma(e, 0.375, 0.5);
+    return __builtin_fma(y * e, c, y);
+}
+
+template <int P, bool GUARD, int UNROLL>
+__global__ __launch_bounds__(BLOCK)
+void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__ mass,
+                     double2 *__restrict__ partial,
+                     uint32_t i_begin, uint32_t i_count,
+                     uint32_t j_begin, uint32_t j_end,
+                     uint32_t js, uint32_t i_tiles, double eps2)
+{
+    constexpr uint32_t IT = BLOCK * P;
+    struct alignas(16) JD { double x, y, m, pad; };
+    __shared__ JD tile[2][TJ];
+
+    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
+    if (!tm.valid) return;
+    const uint32_t t = threadIdx.x;
+    const uint32_t jn = j_end - j_begin;
+    const uint32_t slice_len = (((jn + js - 1) / js + TJ - 1) / TJ) * TJ;
+    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
+    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
+
+    double xi[P], yi[P], ax[P], ay[P];
+    uint32_t li[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        li[p] = tm.i_tile * IT + (uint32_t)p * BLOCK + t;
+        const double2 p0 = pos[i_begin + min(li[p], i_count - 1)];
+        xi[p] = p0.x; yi[p] = p0.y; ax[p] = 0.0; ay[p] = 0.0;
+    }
+    const uint32_t ntiles = (s1 - s0 + TJ - 1) / TJ;
+    {
+        const uint32_t j = s0 + t;
+        double2 pj = make_double2(0.0, 0.0); double mj = 0.0;
+        if (j < s1) { pj = pos[j]; mj = mass[j]; }
+        tile[0][t] = JD{pj.x, pj.y, mj, 0.0};
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < ntiles; ++it) {
+        double2 pn = make_double2(0.0, 0.0); double mn = 0.0;
+        const uint32_t jn1 = s0 + (it + 1) * TJ + t;
+        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }
+        const JD *__restrict__ cur = tile[it & 1];
+#pragma unroll UNROLL
+        for (int jj = 0; jj < TJ; ++jj) {
+            const double xj = cur[jj].x, yj = cur[jj].y, mj = cur[jj].m;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const double dx = xj - xi[p], dy = yj - yi[p];
+                double r2, inv;
+                if constexpr (GUARD) {
+                    r2 = __builtin_fma(dy, dy, dx * dx);
+                    inv = r2 > 0.0 ? rsqrt_f64(r2) : 0.0;
+                } else {
+                    r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
+                    inv = rsqrt_f64(r2);
+                }
+                const double s = (mj * inv) * (inv * inv);
+                ax[p] = __builtin_fma(s, dx, ax[p]);
+                ay[p] = __builtin_fma(s, dy, ay[p]);
+            }
+        }
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = JD{pn.x, pn.y, mn, 0.0};
+        __syncthreads();
+    }
+    double2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (li[p] < i_count) out[li[p]] = make_double2(ax[p], ay[p]);
+}
+
+// ---------------------------------------------------------------------------
+// integrate — Simulation::iterate after attract(), Simulation.hpp:129-163, for
+// the owned block: a = sum of slabs (fixed order); v += a dt; [clamp];
+// [boundary]; x_next = x + v dt.  STRICT keeps every operation individually
+// rounded (the reference build has no FMA contraction) for bit parity.
+// pos_cur/pos_next are full-n replicas; vel/acc are indexed by local i.
+// flags: INTEG_KICK applies the kick (+extras), INTEG_DRIFT writes pos_next;
+// flags = 0 only gathers the slabs into acc (nb_accelerations, KDK bootstrap).
+// ---------------------------------------------------------------------------
+enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
+
+template <typename real> struct vec2_of;
+template <> struct vec2_of<float> { typedef float2 type; };
+template <> struct vec2_of<double> { typedef double2 type; };
+
+template <typename real, bool STRICT>
+__global__ __launch_bounds__(BLOCK)
+void integrate(const typename vec2_of<real>::type *__restrict__ pos_cur,
+               typename vec2_of<real>::type *__restrict__ pos_next,
+               typename vec2_of<real>::type *__restrict__ vel,
+               typename vec2_of<real>::type *__restrict__ acc,
+               const typename vec2_of<real>::type *__restrict__ partial,
+               uint32_t nslabs, uint32_t i_begin, uint32_t i_count,
+               real dt_kick, real dt_drift, int extras, int flags)
+{
+    typedef typename vec2_of<real>::type real2;
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    real2 a = partial[li];
+    for (uint32_t s = 1; s < nslabs; ++s) {
+        const real2 b = partial[(size_t)s * i_count + li];
+        a.x += b.x; a.y += b.y;
+    }
+    acc[li] = a;
+    if (!(flags & INTEG_KICK)) return;              // acceleration gather only
+    real2 v = vel[li];
+    const real2 x = pos_cur[i_begin + li];
+    if constexpr (STRICT) {
+#pragma clang fp contract(off)
+        v.x += a.x * dt_kick;                       // Simulation.hpp:130-131
+        v.y += a.y * dt_kick;
+    } else {
+        v.x = __builtin_fma(a.x, dt_kick, v.x);
+        v.y = __builtin_fma(a.y, dt_kick, v.y);
+    }
+    if (extras & 1) {                               // Simulation.hpp:133-137
+#pragma clang fp contract(off)
+        const real MAX_VELOCITY = (real)1000.0;
+        const real vm = v.x * v.x + v.y * v.y;
+        if (vm > MAX_VELOCITY * MAX_VELOCITY) {
+            const real scale = MAX_VELOCITY / sqrt(vm);
+            v.x *= scale; v.y *= scale;
+        }
+    }
+    if (extras & 2) {                               // Simulation.hpp:140-155
+#pragma clang fp contract(off)
+        const real SOFT_BOUNDARY = (real)80000.0;   // 100000.0f * 0.8f
+        const real d2 = x.x * x.x + x.y * x.y;
+        if (d2 > SOFT_BOUNDARY * SOFT_BOUNDARY) {
+            const real dist = sqrt(d2);
+            const real ratio = dist / SOFT_BOUNDARY;
+            const real force = (real)0.9f * exp(ratio - (real)1.0);
+            const real k = (real)-1.0 / dist;
+            const real fdt = force * dt_kick;
+            v.x += (x.x * k) * fdt;
+            v.y += (x.y * k) * fdt;
+            v.x *= (real)0.9995f;
+            v.y *= (real)0.9995f;
+        }
+    }
+    vel[li] = v;
+    if (flags & INTEG_DRIFT) {
+        real2 xn;
+        if constexpr (STRICT) {
+#pragma clang fp contract(off)
+            xn.x = x.x + v.x * dt_drift;            // Simulation.hpp:161-162
+            xn.y = x.y + v.y * dt_drift;
+        } else {
+            xn.x = __builtin_fma(v.x, dt_drift, x.x);
+            xn.y = __builtin_fma(v.y, dt_drift, x.y);
+        }
+        pos_next[i_begin + li] = xn;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// AoS (64-byte Body records, Body.hpp:6-13) <-> SoA
+// ---------------------------------------------------------------------------
+struct BodyRec { float4 q[4]; };  // pos|pad, vel|pad, acc|pad, mass radius pad pad
+
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void unpack_bodies(const BodyRec *__restrict__ aos, uint32_t n,
+                   typename vec2_of<real>::type *__restrict__ pos, real *__restrict__ mass,
+                   typename vec2_of<real>::type *__restrict__ vel,
+                   typename vec2_of<real>::type *__restrict__ acc,
+                   float *__restrict__ radius,
+                   uint32_t i_begin, uint32_t i_count)
+{
+    typedef typename vec2_of<real>::type real2;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = aos[i].q[0], m = aos[i].q[3];
+    real2 pp; pp.x = (real)p.x; pp.y = (real)p.y;
+    pos[i] = pp;
+    mass[i] = (real)m.x;
+    radius[i] = m.y;
+    if (i >= i_begin && i - i_begin < i_count) {
+        const float4 v = aos[i].q[1], a = aos[i].q[2];
+        real2 vv; vv.x = (real)v.x; vv.y = (real)v.y;
+        real2 aa; aa.x = (real)a.x; aa.y = (real)a.y;
+        vel[i - i_begin] = vv;
+        acc[i - i_begin] = aa;
+    }
+}
+
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void pack_bodies(BodyRec *__restrict__ aos,
+                 const typename vec2_of<real>::type *__restrict__ pos, const real *__restrict__ mass,
+                 const typename vec2_of<real>::type *__restrict__ vel,
+                 const typename vec2_of<real>::type *__restrict__ acc,
+                 const float *__restrict__ radius,
+                 uint32_t i_begin, uint32_t i_count)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    const auto p = pos[i_begin + li];
+    const auto v = vel[li];
+    const auto a = acc[li];
+    BodyRec r;
+    r.q[0] = make_float4((float)p.x, (float)p.y, 0.f, 0.f);
+    r.q[1] = make_float4((float)v.x, (float)v.y, 0.f, 0.f);
+    r.q[2] = make_float4((float)a.x, (float)a.y, 0.f, 0.f);
+    r.q[3] = make_float4((float)mass[i_begin + li], radius[i_begin + li], 0.f, 0.f);
+    aos[li] = r;
+}
+
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void pack_positions(float2 *__restrict__ out, const typename vec2_of<real>::type *__restrict__ pos,
+                    uint32_t i_begin, uint32_t i_count)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    const auto p = pos[i_begin + li];
+    out[li] = make_float2((float)p.x, (float)p.y);
+}
+
+// ---------------------------------------------------------------------------
+// energy — fp64 accumulation whatever the state precision.
+//   ksum[b] = sum over the block's owned i of m v^2 / 2
+//   usum[b] = -1/2 sum_i m_i sum_{j != i} m_j / sqrt(r^2 + eps^2)
+// Per-block partials are summed on the host in block order (deterministic).
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const real *__restrict__ mass,
+                     const typename vec2_of<real>::type *__restrict__ vel,
+                     uint32_t n, uint32_t i_begin, uint32_t i_count, double eps2,
+                     double *__restrict__ ksum, double *__restrict__ usum)
+{
+    struct alignas(16) JD { double x, y, m, pad; };
+    __shared__ JD tile[TJ];
+    __shared__ double red[2][BLOCK / 64];
+    const uint32_t t = threadIdx.x;
+    const uint32_t li = blockIdx.x * BLOCK + t;
+    const bool live = li < i_count;
+    const uint32_t gi = i_begin + (live ? li : i_count - 1);
+    const double xi = (double)pos[gi].x, yi = (double)pos[gi].y;
+    double u = 0.0;
+    for (uint32_t j0 = 0; j0 < n; j0 += TJ) {
+        const uint32_t j = j0 + t;
+        __syncthreads();
+        if (j < n) tile[t] = JD{(double)pos[j].x, (double)pos[j].y, (double)mass[j], 0.0};
+        else tile[t] = JD{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)TJ, n - j0);
+        for (uint32_t jj = 0; jj < cnt; ++jj) {
+            const double dx = tile[jj].x - xi, dy = tile[jj].y - yi;
+            const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
+            const double w = (j0 + jj == gi) ? 0.0 : tile[jj].m;
+            u += w / sqrt(r2);
+        }
+    }
+    double k = 0.0, uu = 0.0;
+    if (live) {
+        const double m = (double)mass[gi];
+        const double vx = (double)vel[li].x, vy = (double)vel[li].y;
+        k = 0.5 * m * (vx * vx + vy * vy);
+        uu = -0.5 * m * u;
+    }
+    // wave64 reduction with shuffles, then across the 4 waves through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        k += __shfl_down(k, off, 64);
+        uu += __shfl_down(uu, off, 64);
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = k; red[1][t >> 6] = uu; }
+    __syncthreads();
+    if (t == 0) {
+        double ks = 0.0, us = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) { ks += red[0][w]; us += red[1][w]; }
+        ksum[blockIdx.x] = ks;
+        usum[blockIdx.x] = us;
+    }
+}
+
+} // namespace nbk

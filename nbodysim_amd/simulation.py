@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's ``Simulation`` surface over the C ABI.
+
+Reference (``Nbodysim/headers/Simulation.hpp:49-75``)::
+
+    class Simulation { public: float dt; size_t frame; std::vector<Body> bodies;
+                       Quadtree quadtree; Simulation(); void step(); };
+    extern std::atomic<float> SIMULATION_DT;          // main.cpp:39, read once per step (:69)
+
+Here ``Simulation(bodies, ...)`` takes the initial bodies instead of the
+hard-coded ``uniform_disc(25000)``; ``step()`` advances one step with the
+module-level ``SIMULATION_DT`` (or an explicit dt) and leaves ``bodies``
+coherent, like the reference's ``step()`` does for its only caller
+(``simulation_thread``, main.cpp:612-635).  ``advance(nsteps)`` is the
+throughput form: it only enqueues work and does not refresh ``bodies``.
+
+All compute happens in ``libnbody_hip.so`` on the GPU; nothing here computes
+forces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+#: the reference's global time step (``std::atomic<float> SIMULATION_DT{0.01f}``, main.cpp:39)
+SIMULATION_DT: float = 0.01
+
+
+class Simulation:
+    """One ``nb_sim`` handle plus the host ``bodies`` view."""
+
+    def __init__(
+        self,
+        bodies: np.ndarray,
+        eps: float = 1.0,           # Simulation.hpp:59 -> Quadtree(theta=1, epsilon=1)
+        precision: str = "fp32",
+        rsqrt: str = "exact",
+        order: str = "tiled",
+        integrator: str = "kick_drift",
+        extras: int = 0,
+        device: int = -1,
+        j_slices: int = 0,
+        i_begin: int = 0,
+        i_count: int = 0,
+        stream: Optional[int] = None,
+        pos_buffers: Optional[tuple] = None,
+    ):
+        lib = L.load()
+        if bodies.dtype != L.BODY_DTYPE:
+            raise TypeError("bodies must be a numpy array of nbodysim_amd.BODY_DTYPE (64-byte Body records)")
+        bodies = np.ascontiguousarray(bodies)
+        p = L.default_params()
+        p.eps = eps
+        p.dt = SIMULATION_DT
+        p.precision = {"fp32": L.NB_FP32, "fp64": L.NB_FP64}[precision]
+        p.rsqrt_mode = {"exact": L.NB_RSQRT_EXACT, "quake": L.NB_RSQRT_QUAKE}[rsqrt]
+        p.sum_order = {"tiled": L.NB_SUM_TILED, "sequential": L.NB_SUM_SEQUENTIAL}[order]
+        p.integrator = {"kick_drift": L.NB_INTEGRATOR_KICK_DRIFT, "kdk": L.NB_INTEGRATOR_KDK}[integrator]
+        p.extras = extras
+        p.device = device
+        p.j_slices = j_slices
+        p.i_begin = i_begin
+        p.i_count = i_count
+        if stream is not None:
+            p.stream = stream
+        if pos_buffers is not None:
+            p.pos_buffers[0], p.pos_buffers[1] = pos_buffers
+        self._lib = lib
+        self._params = p
+        self._h = lib.nb_create(bodies.ctypes.data, bodies.shape[0], C.byref(p))
+        if not self._h:
+            raise L.NBodyError("nb_create", L.NB_EHIP, L.last_error())
+        self.n = int(lib.nb_count(self._h))
+        self.i_begin = int(lib.nb_owned_begin(self._h))
+        self.i_count = int(lib.nb_owned_count(self._h))
+        #: host view of the owned block; refreshed by step() / sync()
+        self.bodies = bodies[self.i_begin : self.i_begin + self.i_count].copy()
+
+    # -- reference surface ---------------------------------------------------
+    @property
+    def frame(self) -> int:
+        return int(self._lib.nb_frame(self._h))
+
+    def step(self, dt: Optional[float] = None) -> None:
+        """``Simulation::step()``: one step, then ``bodies`` is coherent."""
+        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, 1))
+        self.sync()
+
+    # -- throughput / build-defined surface ------------------------------------
+    def advance(self, nsteps: int, dt: Optional[float] = None) -> None:
+        """Enqueue nsteps steps; does not wait and does not refresh ``bodies``."""
+        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, nsteps))
+
+    def wait(self) -> None:
+        L.check("nb_wait", self._lib.nb_wait(self._h))
+
+    def sync(self) -> np.ndarray:
+        L.check("nb_sync", self._lib.nb_sync(self._h, self.bodies.ctypes.data))
+        return self.bodies
+
+    def positions(self) -> np.ndarray:
+        out = np.empty((self.i_count, 2), dtype=np.float32)
+        L.check("nb_sync_positions", self._lib.nb_sync_positions(self._h, out.ctypes.data))
+        return out
+
+    def upload(self, bodies: np.ndarray) -> None:
+        if bodies.dtype != L.BODY_DTYPE or bodies.shape[0] != self.n:
+            raise ValueError("upload needs the n bodies of the whole system")
+        bodies = np.ascontiguousarray(bodies)
+        L.check("nb_upload", self._lib.nb_upload(self._h, bodies.ctypes.data))
+
+    def accelerations(self) -> np.ndarray:
+        """Evaluate a(x) at the current positions (``attract()`` as a direct sum)."""
+        L.check("nb_accelerations", self._lib.nb_accelerations(self._h))
+        return self.sync()["acc"].copy()
+
+    def energy(self) -> tuple:
+        k, u = C.c_double(), C.c_double()
+        L.check("nb_energy", self._lib.nb_energy(self._h, C.byref(k), C.byref(u)))
+        return k.value, u.value
+
+    def dump(self, path: str) -> None:
+        L.check("nb_dump", self._lib.nb_dump(self._h, str(path).encode()))
+
+    # split step for sharded handles
+    def step_begin(self, dt: Optional[float] = None) -> None:
+        L.check("nb_step_begin", self._lib.nb_step_begin(self._h, SIMULATION_DT if dt is None else dt))
+
+    def step_finish(self) -> None:
+        L.check("nb_step_finish", self._lib.nb_step_finish(self._h))
+
+    def pos_buffer(self, which: int = L.NB_POS_CURRENT) -> int:
+        return int(self._lib.nb_pos_buffer(self._h, which) or 0)
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.nb_stream(self._h) or 0)
+
+    def profile(self, on: bool = True) -> None:
+        L.check("nb_profile_enable", self._lib.nb_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> tuple:
+        ms, cnt = C.c_double(), C.c_uint64()
+        L.check("nb_profile_read", self._lib.nb_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)))
+        return ms.value, int(cnt.value)
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(512)
+        L.check("nb_describe", self._lib.nb_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.nb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def write_bodies(path: str, bodies: np.ndarray, frame: int = 0, eps: float = 1.0, dt: float = SIMULATION_DT) -> None:
+    p = L.default_params()
+    p.eps, p.dt = eps, dt
+    bodies = np.ascontiguousarray(bodies)
+    L.check("nb_write_bodies", L.load().nb_write_bodies(str(path).encode(), bodies.ctypes.data, bodies.shape[0], frame, C.byref(p)))
+
+
+def read_bodies(path: str):
+    """Return (bodies, frame, params) of a dump written by nb_dump / nb_write_bodies."""
+    lib = L.load()
+    n, frame, p = C.c_size_t(), C.c_uint64(), L.nb_params()
+    L.check("nb_read_header", lib.nb_read_header(str(path).encode(), C.byref(n), C.byref(frame), C.byref(p)))
+    out = L.bodies_array(n.value)
+    L.check("nb_read_bodies", lib.nb_read_bodies(str(path).encode(), out.ctypes.data, n.value))
+    return out, int(frame.value), p

@@ -1,0 +1,55 @@
+"""Shared fixtures.  `-m gpu` tests need an MI355X; everything else runs on CPU."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def gold():
+    """Golden fixtures produced by the compiled reference (oracle/make_golden.py)."""
+    return {p.stem: np.load(p) for p in GOLD.glob("*.npy")}
+
+
+@pytest.fixture(scope="session")
+def nbo():
+    import nbo as _nbo
+    _nbo.lib()
+    return _nbo
+
+
+def bodies_from_flat(flat):
+    """(n,8) x,y,vx,vy,ax,ay,m,r -> 64-byte Body records."""
+    from nbodysim_amd import bodies_array
+    b = bodies_array(flat.shape[0])
+    b["pos"], b["vel"], b["acc"] = flat[:, 0:2], flat[:, 2:4], flat[:, 4:6]
+    b["mass"], b["radius"] = flat[:, 6], flat[:, 7]
+    return b
+
+
+def flat_from_bodies(b):
+    f = np.zeros((b.shape[0], 8), np.float32)
+    f[:, 0:2], f[:, 2:4], f[:, 4:6] = b["pos"], b["vel"], b["acc"]
+    f[:, 6], f[:, 7] = b["mass"], b["radius"]
+    return f
+
+
+def max_rel(a, b):
+    """max over particles of |a_i - b_i| / |b_i| (2-vector norms): the relative
+    measure of SURVEY §8c, used for the north-star 1e-5 tolerance."""
+    a = np.asarray(a, np.float64).reshape(len(a), -1)
+    b = np.asarray(b, np.float64).reshape(len(b), -1)
+    den = np.linalg.norm(b, axis=1)
+    den = np.where(den > 0, den, 1.0)
+    return float(np.max(np.linalg.norm(a - b, axis=1) / den))
