@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json):
+pair interactions/s of the direct O(N^2) softened-gravity + kick/drift step at
+N = 262 144 (fp32, exact rsqrt, Plummer-2D synthetic data), 1/2/4/8 GPUs.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one force evaluation over all N^2 pairs (self pairs included, as the
+kernel evaluates them) + kick + drift.  N is FIXED as GPUs are added (strong
+scaling, the north-star target): each rank integrates N/gpus particles and the
+ranks all-gather their (x,y) blocks every step (RCCL), overlapped with the
+local-tile force.  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline      fp32 vector-ALU roofline of the force kernel: 14 algorithmic flop
+                per pair x pairs per launch / mean launch duration
+                measured with HIP events on the kernel's stream inside the timed
+                region; peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (C restatement of the reference's pairwise loop, the
+                reference's own arithmetic) timed on this box's host cores over
+                a bounded i-slice of the same workload.  Rank 0, --gpus 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_DEFAULT = 262_144
+EPS, DT, SEED = 0.01, 1e-3, 42
+FLOP_PER_PAIR = 14.0          # algorithmic flop per pair (2-D)
+PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector peak (MI355X_MICROARCH.md, chip table)
+BYTES_PER_PARTICLE_STEP = 36  # read x,y,m,vx,vy + write x,y,vx,vy (fp32)
+
+
+def cpu_baseline(ic, n, target_s=12.0):
+    """Time the oracle on a bounded i-slice of the same N-body workload."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import nbo  # checker / baseline only
+
+    st = nbo.state_from_bodies(ic)
+    threads = nbo.set_threads(0)
+    calib = min(n, 64 * threads)                 # a few i-blocks per thread
+    t0 = time.perf_counter()
+    nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, calib)
+    t_cal = time.perf_counter() - t0
+    rate = calib * n / max(t_cal, 1e-6)
+    islice = int(min(n, max(calib, (rate * target_s / n) // (16 * threads) * (16 * threads))))
+    t0 = time.perf_counter()
+    nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, islice)
+    t = time.perf_counter() - t0
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    return {
+        "value": islice * n / t,
+        "unit": "pair interactions/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"reference pairwise arithmetic (Quake rsqrt, fp32, sequential j) for the first {islice} of {n} "
+                  f"i-particles against all {n} j = {islice * n:.3e} pairs in {t:.2f} s; OpenMP {threads} threads on {model}",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_DEFAULT)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--rsqrt", default="exact", choices=["exact", "quake"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
+    args = ap.parse_args()
+
+    import torch
+
+    import nbodysim_amd as nb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    n = args.n
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    ic = nb.plummer_2d(n, SEED)   # every rank generates the same deterministic ICs
+
+    if world > 1:
+        import torch.distributed as dist
+        from nbodysim_amd.dist import DistributedSimulation
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank)
+        inner = sim.sim
+        advance, wait = sim.advance, sim.wait
+
+        def barrier():
+            dist.barrier()
+    else:
+        sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank)
+        inner = sim
+        advance, wait = sim.advance, sim.wait
+
+        def barrier():
+            pass
+
+    k0, u0 = sim.energy()
+    advance(args.warmup, DT)
+    wait()
+    if not args.no_kernel_events:
+        inner.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    advance(args.steps, DT)
+    wait()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    force_ms, launches = (0.0, 0)
+    if not args.no_kernel_events:
+        force_ms, launches = inner.profile_read()
+        inner.profile(False)
+    k1, u1 = sim.energy()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        pairs_per_step = float(n) * float(n)
+        value = pairs_per_step * args.steps / elapsed
+        # force launches per step on this rank: 1 (single GPU) or up to 3 (local + remote ranges)
+        pairs_this_rank = float(inner.i_count) * float(n) * args.steps
+        if launches and force_ms > 0:
+            kern_s = force_ms * 1e-3
+            achieved = FLOP_PER_PAIR * pairs_this_rank / kern_s / 1e12
+            avg_launch_ms = force_ms / launches
+        else:
+            achieved = FLOP_PER_PAIR * pairs_this_rank / elapsed / 1e12
+            avg_launch_ms = None
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived, written by tools/collect_profile.sh
+        if tfile.exists() and world == 1 and n == N_DEFAULT:
+            try:
+                traffic = json.loads(tfile.read_text()).get("force_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "particle-pair interactions/sec at N=262,144 (direct O(N^2) softened gravity + kick/drift step)",
+            "value": value,
+            "unit": "pair interactions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps_per_s": args.steps / elapsed,
+            "particle_steps_per_s": n * args.steps / elapsed,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f64",
+            "data": "synthetic (3-D Plummer sphere projected to 2-D, mt19937 seed 42, equal masses, eps=0.01, dt=1e-3)",
+            "config": {
+                "workload": f"N={n} {args.precision} direct O(N^2), one MI355X per rank, LDS tile=256" if world == 1 else
+                            f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, all-gather of (x,y) per step",
+                "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled",
+                "parallelism": f"i-block x{world}" if world > 1 else "single GPU",
+                "launch": inner.describe(),
+            },
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2,
+                "unit": "TFLOP/s",
+                "frac": achieved / (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2),
+                "traffic": traffic,
+                "flop_per_pair": FLOP_PER_PAIR,
+                "kernel": "force_tiled_f32" if args.precision == "fp32" else "force_tiled_f64",
+                "avg_launch_ms": avg_launch_ms,
+                "launches": launches,
+                "note": "fp32 vector-ALU bound (no dense contraction for MFMA; the f32 MFMA peak equals the vector peak, 157.3 TF); "
+                        "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B",
+                "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
+            },
+            "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
+                       "steps": args.warmup + args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ic, n)
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,7 +72,7 @@ extern "C" void nb_params_default(nb_params *p)
 // ---------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------
-struct ForceJob { uint32_t j_begin, j_end, js, slab0; };
+struct ForceJob { uint32_t j_begin, j_end, js, slab0; int P; uint32_t i_tiles; };
 
 struct nb_sim {
     nb_params p;
@@ -97,8 +97,7 @@ struct nb_sim {
     double *ered_dev = nullptr;     // energy partials
     size_t ered_blocks = 0;
 
-    // launch geometry
-    int P = 2;
+    // launch geometry (per job: particles per lane and j-slices)
     ForceJob job_all{}, job_local{}, job_before{}, job_after{};
     uint32_t slabs_all = 0, slabs_two_phase = 0;
 
@@ -122,45 +121,60 @@ static int bind(const nb_sim *s)
     return NB_OK;
 }
 
-// Choose j-slices so that the force grid has about 2 workgroups (8 waves) per CU.
-static uint32_t pick_slices(uint32_t i_tiles, uint32_t jn, int cus, int forced)
+// Launch geometry of one force job (DESIGN.md §launch geometry).  The kernel is
+// VALU-bound, so what matters is (a) enough independent work per lane — 2P
+// particles per lane, P = 4 measured best — and (b) enough workgroups in flight
+// to keep 5-8 waves per SIMD issuing and to even out the tail: about 16
+// workgroups per CU.  When i-particles are scarce (sharded or small runs) the
+// j range is cut into more slices, and P drops only when the slices would get
+// shorter than two LDS tiles.
+static uint32_t legal_slices(uint32_t js)
 {
-    uint32_t max_js = jn / TJ ? jn / TJ : 1;  // every slice gets at least one full tile
-    uint32_t js = 1;
-    if (forced > 0) js = (uint32_t)forced;
-    else {
-        const uint32_t target = 2u * (uint32_t)cus;
-        while (i_tiles * js < target && js < max_js) js = js < 8 ? js * 2 : js + 8;
+    // decode_block handles 1, 2, 4 or a multiple of 8
+    if (js >= 8) return (js / 8) * 8;
+    if (js >= 4) return 4;
+    if (js >= 2) return 2;
+    return 1;
+}
+
+static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t slab0)
+{
+    ForceJob j{jb, je, 0, slab0, 1, 0};
+    const uint32_t ic = (uint32_t)s->i_count;
+    if (je <= jb) return j;
+    const uint32_t jn = je - jb;
+    if (s->p.sum_order == NB_SUM_SEQUENTIAL) { j.js = 1; j.P = 1; j.i_tiles = (ic + BLOCK - 1) / BLOCK; return j; }
+    const uint32_t lanes_i = s->fp64 ? 1u : 2u;                 // particles per lane per P
+    const uint32_t target = 16u * (uint32_t)s->cus;             // workgroups
+    const uint32_t max_js = jn / TJ ? jn / TJ : 1;              // >= one full tile per slice
+    const char *envp = getenv("NB_FORCE_P");
+    const int forced_p = envp ? atoi(envp) : 0;
+    const int pmax = s->fp64 ? 2 : 4;
+    int best_p = 1; uint32_t best_js = 1;
+    for (int P = pmax; P >= 1; P >>= 1) {
+        if (forced_p > 0 && P != forced_p && !(forced_p > pmax && P == pmax)) continue;
+        const uint32_t i_tiles = (ic + BLOCK * lanes_i * P - 1) / (BLOCK * lanes_i * P);
+        uint32_t want = (target + i_tiles - 1) / i_tiles;
+        if (s->p.j_slices > 0) want = (uint32_t)s->p.j_slices;
+        uint32_t js = legal_slices(want < 1 ? 1 : want);
+        const uint32_t cap = legal_slices(max_js >= 2 && forced_p == 0 && s->p.j_slices <= 0 ? max_js / 2 : max_js);
+        best_p = P; best_js = js > cap ? cap : js;
+        if (js <= cap || forced_p > 0) break;                   // enough slices at this P
     }
-    if (js > max_js) js = max_js;
-    // legal values for decode_block: 1, 2, 4 or a multiple of 8
-    if (js >= 8) js = (js / 8) * 8;
-    else if (js == 3) js = 2;
-    else if (js >= 5) js = 4;
-    return js ? js : 1;
+    j.P = best_p;
+    j.js = best_js;
+    j.i_tiles = (ic + BLOCK * lanes_i * j.P - 1) / (BLOCK * lanes_i * j.P);
+    return j;
 }
 
 static void plan(nb_sim *s)
 {
-    const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     const uint32_t n = (uint32_t)s->n, ib = (uint32_t)s->i_begin, ic = (uint32_t)s->i_count;
-    // lanes own 2P particles (fp32) or P (fp64); fewer per lane when i is scarce
-    const char *envp = getenv("NB_FORCE_P");
-    if (s->fp64) s->P = ic >= (uint32_t)s->cus * BLOCK * 2 ? 2 : 1;
-    else s->P = ic >= (uint32_t)s->cus * BLOCK * 4 ? 2 : 1;
-    if (envp && (atoi(envp) == 1 || atoi(envp) == 2)) s->P = atoi(envp);
-    const uint32_t per_tile = s->fp64 ? BLOCK * s->P : BLOCK * 2 * s->P;
-    const uint32_t i_tiles = (ic + per_tile - 1) / per_tile;
-    auto mk = [&](uint32_t jb, uint32_t je, uint32_t slab0) {
-        ForceJob j{jb, je, 0, slab0};
-        if (je > jb) j.js = seq ? 1 : pick_slices(i_tiles, je - jb, s->cus, s->p.j_slices);
-        return j;
-    };
-    s->job_all = mk(0, n, 0);
+    s->job_all = plan_job(s, 0, n, 0);
     s->slabs_all = s->job_all.js;
-    s->job_local = mk(ib, ib + ic, 0);
-    s->job_before = mk(0, ib, s->job_local.js);
-    s->job_after = mk(ib + ic, n, s->job_local.js + s->job_before.js);
+    s->job_local = plan_job(s, ib, ib + ic, 0);
+    s->job_before = plan_job(s, 0, ib, s->job_local.js);
+    s->job_after = plan_job(s, ib + ic, n, s->job_local.js + s->job_before.js);
     s->slabs_two_phase = s->job_local.js + s->job_before.js + s->job_after.js;
 }
 
@@ -324,8 +338,9 @@ static int prof_collect(nb_sim *s)
 // force launch
 // ---------------------------------------------------------------------------
 template <int P, int RSQ, bool GUARD>
-static void launch_tiled_f32(nb_sim *s, const ForceJob &j, uint32_t i_tiles, float eps2)
+static void launch_tiled_f32(nb_sim *s, const ForceJob &j, float eps2)
 {
+    const uint32_t i_tiles = j.i_tiles;
     const uint32_t grid = grid_blocks(i_tiles, j.js);
     float2 *out = (float2 *)s->partial + (size_t)j.slab0 * s->i_count;
     force_tiled_f32<P, RSQ, GUARD, 8><<<grid, BLOCK, 0, s->stream>>>(
@@ -334,8 +349,9 @@ static void launch_tiled_f32(nb_sim *s, const ForceJob &j, uint32_t i_tiles, flo
 }
 
 template <int P, bool GUARD>
-static void launch_tiled_f64(nb_sim *s, const ForceJob &j, uint32_t i_tiles, double eps2)
+static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
 {
+    const uint32_t i_tiles = j.i_tiles;
     const uint32_t grid = grid_blocks(i_tiles, j.js);
     double2 *out = (double2 *)s->partial + (size_t)j.slab0 * s->i_count;
     force_tiled_f64<P, GUARD, 4><<<grid, BLOCK, 0, s->stream>>>(
@@ -352,9 +368,8 @@ static int launch_force(nb_sim *s, const ForceJob &j)
     const uint32_t ic = (uint32_t)s->i_count;
     if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
-        const uint32_t i_tiles = (ic + BLOCK * s->P - 1) / (BLOCK * s->P);
-        if (s->P == 2) { if (guard) launch_tiled_f64<2, true>(s, j, i_tiles, eps2); else launch_tiled_f64<2, false>(s, j, i_tiles, eps2); }
-        else           { if (guard) launch_tiled_f64<1, true>(s, j, i_tiles, eps2); else launch_tiled_f64<1, false>(s, j, i_tiles, eps2); }
+        if (j.P == 2) { if (guard) launch_tiled_f64<2, true>(s, j, eps2); else launch_tiled_f64<2, false>(s, j, eps2); }
+        else          { if (guard) launch_tiled_f64<1, true>(s, j, eps2); else launch_tiled_f64<1, false>(s, j, eps2); }
     } else {
         const float eps2 = s->p.eps * s->p.eps;   // Quadtree.hpp:19  e_sq(epsilon * epsilon)
         if (s->p.sum_order == NB_SUM_SEQUENTIAL) {
@@ -367,16 +382,15 @@ static int launch_force(nb_sim *s, const ForceJob &j)
                 force_seq_f32<RSQ_EXACT><<<grid, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (const float *)s->mass, out,
                                                                           (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, eps2);
         } else {
-            const uint32_t i_tiles = (ic + BLOCK * 2 * s->P - 1) / (BLOCK * 2 * s->P);
             const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
 #define NB_DISPATCH(PP)                                                                           \
             do {                                                                                  \
-                if (quake) { if (guard) launch_tiled_f32<PP, RSQ_QUAKE, true>(s, j, i_tiles, eps2);  \
-                             else       launch_tiled_f32<PP, RSQ_QUAKE, false>(s, j, i_tiles, eps2); } \
-                else       { if (guard) launch_tiled_f32<PP, RSQ_EXACT, true>(s, j, i_tiles, eps2);  \
-                             else       launch_tiled_f32<PP, RSQ_EXACT, false>(s, j, i_tiles, eps2); } \
+                if (quake) { if (guard) launch_tiled_f32<PP, RSQ_QUAKE, true>(s, j, eps2);  \
+                             else       launch_tiled_f32<PP, RSQ_QUAKE, false>(s, j, eps2); } \
+                else       { if (guard) launch_tiled_f32<PP, RSQ_EXACT, true>(s, j, eps2);  \
+                             else       launch_tiled_f32<PP, RSQ_EXACT, false>(s, j, eps2); } \
             } while (0)
-            if (s->P == 2) NB_DISPATCH(2); else NB_DISPATCH(1);
+            if (j.P == 4) NB_DISPATCH(4); else if (j.P == 2) NB_DISPATCH(2); else NB_DISPATCH(1);
 #undef NB_DISPATCH
         }
     }
@@ -620,15 +634,15 @@ extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *forc
 extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
 {
     if (!s || !buf || !buflen) { nb_set_error("nb_describe: NULL argument"); return NB_EINVAL; }
-    const uint32_t per_tile = s->fp64 ? BLOCK * s->P : BLOCK * 2 * s->P;
-    const uint32_t i_tiles = ((uint32_t)s->i_count + per_tile - 1) / per_tile;
+    const ForceJob &a = s->job_all;
+    const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
-             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | two-phase slabs local/before/after=%u/%u/%u | CUs=%d",
+             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
+             "two-phase P/slices local=%d/%u before=%d/%u after=%d/%u | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
-             s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact",
-             s->p.sum_order == NB_SUM_SEQUENTIAL ? "sequential" : "tiled",
-             BLOCK, s->fp64 ? s->P : 2 * s->P, i_tiles, s->job_all.js,
-             s->p.sum_order == NB_SUM_SEQUENTIAL ? ((uint32_t)s->i_count + BLOCK - 1) / BLOCK : grid_blocks(i_tiles, s->job_all.js),
-             TJ, s->job_local.js, s->job_before.js, s->job_after.js, s->cus);
+             s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
+             BLOCK, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
+             seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
+             s->job_local.P, s->job_local.js, s->job_before.P, s->job_before.js, s->job_after.P, s->job_after.js, s->cus);
     return NB_OK;
 }

@@ -91,12 +91,12 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 // Lane t of tile T owns particles  i_begin + T*IT + p*512 + 2t + {0,1},  p < P.
 // ---------------------------------------------------------------------------
 template <int P, int RSQ, bool GUARD, int UNROLL>
-__global__ __launch_bounds__(BLOCK)
-void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
-                     float2 *__restrict__ partial,
-                     uint32_t i_begin, uint32_t i_count,
-                     uint32_t j_begin, uint32_t j_end,
-                     uint32_t js, uint32_t i_tiles, float eps2)
+__device__ __forceinline__
+void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                          float2 *__restrict__ partial,
+                          uint32_t i_begin, uint32_t i_count,
+                          uint32_t j_begin, uint32_t j_end,
+                          uint32_t js, uint32_t i_tiles, float eps2)
 {
     constexpr uint32_t IT = BLOCK * 2 * P;
     __shared__ v4f tile[2][TJ];
@@ -192,6 +192,128 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
     }
 }
 
+template <int P, int RSQ, bool GUARD, int UNROLL>
+__global__ __launch_bounds__(BLOCK)
+void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                     float2 *__restrict__ partial,
+                     uint32_t i_begin, uint32_t i_count,
+                     uint32_t j_begin, uint32_t j_end,
+                     uint32_t js, uint32_t i_tiles, float eps2)
+{
+    force_tiled_f32_body<P, RSQ, GUARD, UNROLL>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2);
+}
+
+// ---------------------------------------------------------------------------
+// force_wave_f32 — barrier-free variant of the fast path: ONE wave64 per
+// workgroup, each wave stages its own 64-particle j-chunks in a private 1 KiB
+// LDS tile (ds_write_b128 once per chunk, 64 broadcast ds_read_b128 back), so
+// there is no s_barrier anywhere and the 8 waves a SIMD can hold drift freely
+// and keep the VALU issuing (the kernel is VALU-bound: 9 packed ops at 4 cycles
+// + 2 v_rsq_f32 at 8 cycles per 128 pairs — DESIGN.md §roofline).
+// Same arithmetic, same slabs, same block decode as force_tiled_f32; a lane
+// owns 2P particles: i_begin + T*(128P) + p*128 + 2*lane + {0,1}.
+// ---------------------------------------------------------------------------
+constexpr int WAVE = 64;
+
+template <int P, int RSQ, bool GUARD, int UNROLL>
+__device__ __forceinline__
+void force_wave_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                         float2 *__restrict__ partial,
+                         uint32_t i_begin, uint32_t i_count,
+                         uint32_t j_begin, uint32_t j_end,
+                         uint32_t js, uint32_t i_tiles, float eps2)
+{
+    constexpr uint32_t IT = WAVE * 2 * P;
+    __shared__ v4f tile[WAVE];
+
+    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
+    if (!tm.valid) return;
+    const uint32_t t = threadIdx.x;
+
+    const uint32_t jn = j_end - j_begin;
+    const uint32_t slice_len = (((jn + js - 1) / js + WAVE - 1) / WAVE) * WAVE;
+    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
+    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
+
+    v2f xi[P], yi[P], ax[P], ay[P];
+    uint32_t li[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        li[p] = tm.i_tile * IT + (uint32_t)p * (WAVE * 2) + 2u * t;
+        const uint32_t l0 = min(li[p], i_count - 1), l1 = min(li[p] + 1, i_count - 1);
+        const float2 p0 = pos[i_begin + l0], p1 = pos[i_begin + l1];
+        xi[p] = (v2f){p0.x, p1.x};
+        yi[p] = (v2f){p0.y, p1.y};
+        ax[p] = (v2f){0.f, 0.f};
+        ay[p] = (v2f){0.f, 0.f};
+    }
+    const v2f e2 = {eps2, eps2};
+
+    const uint32_t nchunks = (s1 - s0 + WAVE - 1) / WAVE;
+    float2 pn = make_float2(0.f, 0.f);
+    float mn = 0.f;
+    if (s0 + t < s1) { pn = pos[s0 + t]; mn = mass[s0 + t]; }
+
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        tile[t] = (v4f){pn.x, pn.y, mn, mn};      // this wave's chunk c (same-wave LDS order: no barrier)
+        const uint32_t jn1 = s0 + (c + 1) * WAVE + t;
+        pn = make_float2(0.f, 0.f); mn = 0.f;
+        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }   // chunk c+1 in flight behind the compute
+#pragma unroll UNROLL
+        for (int jj = 0; jj < WAVE; ++jj) {
+            const v4f q = tile[jj];
+            const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, mj = {q.z, q.w};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const v2f dx = xj - xi[p];
+                const v2f dy = yj - yi[p];
+                v2f r2, inv;
+                if constexpr (GUARD) {
+                    r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+                    if constexpr (RSQ == RSQ_EXACT)
+                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else
+                        inv = quake_rsqrt2(r2);
+                    inv.x = r2.x > 0.f ? inv.x : 0.f;
+                    inv.y = r2.y > 0.f ? inv.y : 0.f;
+                } else {
+                    r2 = __builtin_elementwise_fma(dx, dx, e2);
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    if constexpr (RSQ == RSQ_EXACT)
+                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else
+                        inv = quake_rsqrt2(r2);
+                }
+                const v2f inv2 = inv * inv;
+                const v2f s = (mj * inv) * inv2;
+                ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
+                ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
+            }
+        }
+    }
+
+    float2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (li[p] + 1 < i_count) {
+            *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+        } else if (li[p] < i_count) {
+            out[li[p]] = make_float2(ax[p].x, ay[p].x);
+        }
+    }
+}
+
+template <int P, int RSQ, bool GUARD, int UNROLL>
+__global__ __launch_bounds__(WAVE)
+void force_wave_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                    float2 *__restrict__ partial,
+                    uint32_t i_begin, uint32_t i_count,
+                    uint32_t j_begin, uint32_t j_end,
+                    uint32_t js, uint32_t i_tiles, float eps2)
+{
+    force_wave_f32_body<P, RSQ, GUARD, UNROLL>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2);
+}
+
 // ---------------------------------------------------------------------------
 // force_seq_f32 — reference summation order (NB_SUM_SEQUENTIAL).
 // One lane per i, j ascending over the WHOLE range in one running sum, every
@@ -235,7 +357,7 @@ void force_seq_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
             const float tt = r_sq + eps2;
             float inv;
             if constexpr (RSQ == RSQ_QUAKE) inv = quake_rsqrt(tt);
-            else inv = 1.0f / __fsqrt_rn(tt);
+            else inv = 1.0f / sqrtf(tt);   // correctly rounded sqrt and divide (hipcc default)
             const float inv3 = inv * inv * inv;
             const float s = q.z * inv3;
             const float cx = rx * s, cy = ry * s;

@@ -1,0 +1,153 @@
+"""One-process-per-GPU sharding of the hot path.
+
+i-particles are independent, so each rank integrates one contiguous block and
+holds a full-n replica of the positions; the only exchange per step is an
+all-gather of the freshly drifted (x, y) blocks.  The collective is
+``torch.distributed.all_gather_into_tensor`` — RCCL over xGMI with the ``nccl``
+backend, gloo on CPU for the tests — writing IN PLACE into the device replica
+the force kernel reads, on the process group's communication stream, while the
+local-tile force of the next step already runs on the compute stream:
+
+    step k:   [compute]  force(local j-block) ......... wait(AG k-1) force(remote) integrate
+              [comm   ]  ... all-gather of step k-1's positions ...          \\-> all-gather k
+
+The reference has no distributed code at all; this layer is new.
+PyTorch is plumbing here (device buffers, streams, the process group); the
+force/integrate work is the C ABI's.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Contiguous, equal blocks of the particle index range (n % world == 0)."""
+
+    n: int
+    world: int
+    rank: int
+
+    def __post_init__(self):
+        if self.world < 1 or not (0 <= self.rank < self.world):
+            raise ValueError(f"bad rank/world {self.rank}/{self.world}")
+        if self.n % self.world != 0:
+            raise ValueError(f"n={self.n} must be a multiple of the world size {self.world} "
+                             "(equal blocks keep the all-gather a single collective)")
+
+    @property
+    def i_count(self) -> int:
+        return self.n // self.world
+
+    @property
+    def i_begin(self) -> int:
+        return self.rank * self.i_count
+
+    @property
+    def i_end(self) -> int:
+        return self.i_begin + self.i_count
+
+    def block(self, rank: int) -> slice:
+        c = self.n // self.world
+        return slice(rank * c, (rank + 1) * c)
+
+
+def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False):
+    """All-gather the owned block of ``full`` (an (n, 2) torch tensor, any device)
+    into every rank's ``full`` in place.  Returns the Work handle if async."""
+    import torch.distributed as dist
+
+    if plan.world == 1:
+        return None
+    own = full[plan.i_begin : plan.i_end]
+    return dist.all_gather_into_tensor(full, own, group=group, async_op=async_op)
+
+
+class DistributedSimulation:
+    """Sharded ``Simulation``: one rank of a ``torch.distributed`` job, one GPU."""
+
+    def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
+                 order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0):
+        import torch
+        import torch.distributed as dist
+
+        from .simulation import Simulation
+
+        self.dist = dist
+        self.torch = torch
+        self.group = group
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.plan = ShardPlan(int(bodies.shape[0]), world, rank)
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        dtype = torch.float64 if precision == "fp64" else torch.float32
+        # full-n position replicas owned by torch so the collective can write them
+        self.pos = [torch.empty((self.plan.n, 2), dtype=dtype, device=self.device) for _ in range(2)]
+        self.stream = torch.cuda.Stream(self.device)
+        self.sim = Simulation(
+            bodies, eps=eps, precision=precision, rsqrt=rsqrt, order=order, device=device_index, j_slices=j_slices,
+            i_begin=self.plan.i_begin, i_count=self.plan.i_count, stream=self.stream.cuda_stream,
+            pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
+        )
+        self._cur = 0          # index into self.pos of the library's CURRENT replica
+        self._pending = None   # Work of the all-gather filling the CURRENT replica
+        assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
+
+    @property
+    def frame(self) -> int:
+        return self.sim.frame
+
+    def step(self, dt: Optional[float] = None) -> None:
+        """One sharded step; only enqueues (no host sync)."""
+        with self.torch.cuda.stream(self.stream):
+            self.sim.step_begin(dt)          # local j-block: overlaps the in-flight all-gather
+            if self._pending is not None:
+                self._pending.wait()         # compute stream waits for the remote blocks
+                self._pending = None
+            self.sim.step_finish()           # remote j-blocks, kick, drift -> NEXT becomes CURRENT
+            self._cur ^= 1
+            self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
+
+    def advance(self, nsteps: int, dt: Optional[float] = None) -> None:
+        for _ in range(nsteps):
+            self.step(dt)
+
+    def wait(self) -> None:
+        with self.torch.cuda.stream(self.stream):
+            if self._pending is not None:
+                self._pending.wait()
+                self._pending = None
+        self.stream.synchronize()
+
+    def sync(self) -> np.ndarray:
+        """Owned block as Body records (each GPU copies back only its block)."""
+        self.wait()
+        return self.sim.sync()
+
+    def gather_bodies(self) -> Optional[np.ndarray]:
+        """All blocks on every rank (host-side object gather; for tests / dumps)."""
+        mine = self.sync().copy()
+        if self.plan.world == 1:
+            return mine
+        parts = [None] * self.plan.world
+        self.dist.all_gather_object(parts, mine, group=self.group)
+        return np.concatenate(parts)
+
+    def energy(self) -> tuple:
+        self.wait()
+        k, u = self.sim.energy()
+        if self.plan.world > 1:
+            t = self.torch.tensor([k, u], dtype=self.torch.float64, device=self.device)
+            self.dist.all_reduce(t, group=self.group)
+            k, u = float(t[0]), float(t[1])
+        return k, u
+
+    def close(self) -> None:
+        self.wait()
+        self.sim.close()

@@ -1,0 +1,107 @@
+/* nbody_main.c — plain-C host driver over the C ABI (include/nbody.h).
+ *
+ * The reference's only host is a raylib GUI whose simulation thread does
+ *     simulation->step();  SHARED_BODIES = simulation->bodies;     (main.cpp:621-627)
+ * This is the headless equivalent: init -> step() loop -> dump, all in C, all
+ * compute in libnbody_hip.so.
+ *
+ *   nbody_main [-n N] [-s steps] [-dt DT] [-eps EPS] [-seed S] [-fp64] [-quake]
+ *              [-sequential] [-kdk] [-dump FILE] [-load FILE] [-sync-every K]
+ */
+#include "nbody.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
+#define CHECK(call) do { int rc_ = (call); if (rc_ != NB_OK) DIE("%s -> %d: %s", #call, rc_, nb_last_error()); } while (0)
+
+int main(int argc, char **argv)
+{
+    size_t n = 65536;
+    int steps = 20, sync_every = 0;
+    unsigned seed = 42;
+    const char *dump = NULL, *load = NULL;
+    nb_params p;
+    nb_params_default(&p);
+    p.eps = 0.01f;
+    p.dt = 1e-3f;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-n") && i + 1 < argc) n = (size_t)strtoull(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "-s") && i + 1 < argc) steps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-dt") && i + 1 < argc) p.dt = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "-eps") && i + 1 < argc) p.eps = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "-seed") && i + 1 < argc) seed = (unsigned)strtoul(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "-fp64")) p.precision = NB_FP64;
+        else if (!strcmp(argv[i], "-quake")) p.rsqrt_mode = NB_RSQRT_QUAKE;
+        else if (!strcmp(argv[i], "-sequential")) p.sum_order = NB_SUM_SEQUENTIAL;
+        else if (!strcmp(argv[i], "-kdk")) p.integrator = NB_INTEGRATOR_KDK;
+        else if (!strcmp(argv[i], "-dump") && i + 1 < argc) dump = argv[++i];
+        else if (!strcmp(argv[i], "-load") && i + 1 < argc) load = argv[++i];
+        else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
+        else DIE("unknown argument %s", argv[i]);
+    }
+
+    nb_body *bodies;
+    if (load) {
+        uint64_t frame;
+        nb_params fp;
+        CHECK(nb_read_header(load, &n, &frame, &fp));
+        bodies = (nb_body *)malloc(n * sizeof *bodies);
+        if (!bodies) DIE("out of memory");
+        CHECK(nb_read_bodies(load, bodies, n));
+        printf("loaded %zu bodies (frame %llu) from %s\n", n, (unsigned long long)frame, load);
+    } else {
+        bodies = (nb_body *)malloc(n * sizeof *bodies);
+        if (!bodies) DIE("out of memory");
+        CHECK(nb_plummer_2d(bodies, n, seed));
+    }
+
+    nb_sim *sim = nb_create(bodies, n, &p);
+    if (!sim) DIE("nb_create: %s", nb_last_error());
+    char desc[512];
+    CHECK(nb_describe(sim, desc, sizeof desc));
+    printf("%s\n", desc);
+
+    double k0, u0, k1, u1;
+    CHECK(nb_energy(sim, &k0, &u0));
+    CHECK(nb_step(sim, p.dt, 2));           /* warm-up */
+    CHECK(nb_wait(sim));
+    const double t0 = now_s();
+    if (sync_every > 0) {                   /* the reference's pattern: step, then refresh bodies */
+        for (int s = 0; s < steps; ++s) {
+            CHECK(nb_step(sim, p.dt, 1));
+            if ((s + 1) % sync_every == 0) CHECK(nb_sync(sim, bodies));
+        }
+    } else {
+        CHECK(nb_step(sim, p.dt, steps));
+    }
+    CHECK(nb_wait(sim));
+    const double t1 = now_s();
+    CHECK(nb_energy(sim, &k1, &u1));
+    CHECK(nb_sync(sim, bodies));
+
+    const double per = (t1 - t0) / steps;
+    printf("frame=%llu  %.3f ms/step  %.2f steps/s  %.3e pair interactions/s  %.2f TFLOP/s (14 flop/pair)\n",
+           (unsigned long long)nb_frame(sim), per * 1e3, 1.0 / per, (double)n * (double)n / per,
+           14.0 * (double)n * (double)n / per / 1e12);
+    printf("energy: E0=%.9e  E1=%.9e  drift=%.3e\n", k0 + u0, k1 + u1, (k1 + u1 - k0 - u0) / (k0 + u0));
+    printf("body[0]: pos=(%.6f, %.6f) vel=(%.6f, %.6f) acc=(%.6f, %.6f)\n", bodies[0].pos.x, bodies[0].pos.y,
+           bodies[0].vel.x, bodies[0].vel.y, bodies[0].acc.x, bodies[0].acc.y);
+    if (dump) {
+        CHECK(nb_dump(sim, dump));
+        printf("dumped to %s\n", dump);
+    }
+    nb_destroy(sim);
+    free(bodies);
+    return 0;
+}

@@ -1,0 +1,38 @@
+// sim_thread_example.cpp — the reference's simulation_thread pattern
+// (main.cpp:612-635) compiled against the adaptor: step(), lock, copy bodies.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "Simulation.hpp"
+
+std::atomic<float> SIMULATION_DT{0.01f};   // main.cpp:39
+std::mutex UPDATE_LOCK;                    // main.cpp:38
+std::vector<Body> SHARED_BODIES;           // main.cpp:40
+
+static void simulation_thread(std::shared_ptr<Simulation> simulation, int frames)
+{
+    for (int f = 0; f < frames; ++f) {
+        simulation->step();
+        {
+            std::lock_guard<std::mutex> lock(UPDATE_LOCK);
+            SHARED_BODIES = simulation->bodies;
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 4096;
+    std::vector<Body> init(n);
+    if (nb_plummer_2d(reinterpret_cast<nb_body *>(init.data()), n, 42) != NB_OK) return 1;
+    SIMULATION_DT.store(1e-3f);
+    auto simulation = std::make_shared<Simulation>(std::move(init), 0.05f);
+    simulation_thread(simulation, 10);
+    std::printf("frame=%zu bodies=%zu body0=(%.6f, %.6f)\n", simulation->frame, SHARED_BODIES.size(),
+                SHARED_BODIES[0].pos.x, SHARED_BODIES[0].pos.y);
+    return 0;
+}

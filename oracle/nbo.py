@@ -56,6 +56,30 @@ def build(force: bool = False) -> Path:
     return LIB
 
 
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants a share of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    n = min(n, max(1, q // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 _lib = None
 
 
@@ -75,6 +99,7 @@ def lib() -> C.CDLL:
         l.nbo_step_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
         l.nbo_kick_drift_f32.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int]
         l.nbo_energy_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        l.nbo_set_threads(int(os.environ.get("NBO_THREADS", host_threads())))
         _lib = l
     return _lib
 
@@ -154,7 +179,8 @@ def energy(st: dict, eps: float):
 
 
 def set_threads(n: int) -> int:
-    return lib().nbo_set_threads(n)
+    """n <= 0 restores the default (host_threads())."""
+    return lib().nbo_set_threads(n if n > 0 else int(os.environ.get("NBO_THREADS", host_threads())))
 
 
 # ---------------------------------------------------------------------------

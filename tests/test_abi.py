@@ -1,0 +1,160 @@
+"""CPU: the C-ABI library loads, exports every symbol include/nbody.h declares,
+and its host-only entry points behave; compute entry points fail loudly without a GPU."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, flat_from_bodies
+
+import nbodysim_amd as nb
+from nbodysim_amd import _lib as L
+
+HEADER = (ROOT / "include" / "nbody.h").read_text()
+
+
+def declared_symbols():
+    # every `name(` at the start of a declaration that begins with nb_
+    names = set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", HEADER))
+    return sorted(names)
+
+
+def test_header_and_binding_agree():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    assert set(syms) == set(L.PROTOTYPES), set(syms) ^ set(L.PROTOTYPES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(str(L.LIB_PATH))
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"libnbody_hip.so lacks {name}"
+    out = subprocess.run(["nm", "-D", "--defined-only", str(L.LIB_PATH)], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nb_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+
+
+def test_library_contains_gfx950_code_object():
+    blob = L.LIB_PATH.read_bytes()
+    assert b"gfx950" in blob and b"force_tiled_f32" in blob
+
+
+def test_abi_version_and_defaults():
+    lib = nb.load()
+    assert lib.nb_abi_version() == L.NB_ABI_VERSION
+    p = L.default_params()
+    assert p.struct_size == C.sizeof(L.nb_params)
+    assert p.eps == 1.0 and abs(p.dt - 0.01) < 1e-9          # Simulation.hpp:59, main.cpp:39
+    assert (p.precision, p.rsqrt_mode, p.sum_order, p.extras) == (L.NB_FP32, L.NB_RSQRT_EXACT, L.NB_SUM_TILED, 0)
+
+
+def test_body_dtype_matches_reference_layout():
+    import json
+    lay = json.loads((ROOT / "tests" / "golden" / "layout.json").read_text())
+    dt = L.BODY_DTYPE
+    assert dt.itemsize == lay["sizeof_Body"] == 64
+    assert dt.fields["pos"][1] == lay["off_pos"] and dt.fields["vel"][1] == lay["off_vel"]
+    assert dt.fields["acc"][1] == lay["off_acc"] and dt.fields["mass"][1] == lay["off_mass"]
+    assert dt.fields["radius"][1] == lay["off_radius"]
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "nbody.h"\nint main(void){nb_params p; nb_params_default(&p); return sizeof(nb_body)==64?0:1;}\n')
+    for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++17")):
+        r = subprocess.run([cc, std, "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", "-x", "c" if cc == "gcc" else "c++",
+                            str(src), "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_plummer_generator_reproduces_fixture(gold):
+    got = flat_from_bodies(nb.plummer_2d(1024, 42))
+    assert np.array_equal(got.view(np.uint32), gold["ic_plummer_1024"].view(np.uint32))
+    got = flat_from_bodies(nb.plummer_2d(4096, 7))
+    assert np.array_equal(got.view(np.uint32), gold["ic_plummer_4096"].view(np.uint32))
+
+
+def test_plummer_statistics():
+    b = nb.plummer_2d(65536, 1)
+    assert abs(b["mass"].astype(np.float64).sum() - 1.0) < 1e-6
+    assert (b["radius"] == 0).all() and (b["acc"] == 0).all()
+    r = np.linalg.norm(b["pos"].astype(np.float64), axis=1)
+    # projected Plummer (a=1): half-mass cylinder radius R_h = 1; allow sampling noise
+    assert abs(np.median(r) - 1.0) < 0.02
+    assert r.max() <= 20.0 + 1e-4
+    # 2-D velocity dispersion of a Plummer sphere: <v^2>_3D = 3 pi / 32 -> 2/3 of it in projection
+    v2 = (b["vel"].astype(np.float64) ** 2).sum(1).mean()
+    assert abs(v2 - (2.0 / 3.0) * 3.0 * np.pi / 32.0) < 0.01
+    # padding bytes are zero
+    raw = b.view(np.uint8).reshape(-1, 64)
+    assert not raw[:, 8:16].any() and not raw[:, 24:32].any() and not raw[:, 40:48].any() and not raw[:, 56:64].any()
+
+
+def test_dump_format_round_trip(tmp_path):
+    b = nb.plummer_2d(1000, 3)
+    b["acc"][:, 0] = 1.5
+    path = tmp_path / "state.nbd"
+    nb.write_bodies(path, b, frame=17, eps=0.05, dt=1e-3)
+    raw = path.read_bytes()
+    assert len(raw) == 64 + 1000 * 64 and raw[:8] == b"NBODYAMD"
+    back, frame, p = nb.read_bodies(path)
+    assert frame == 17 and abs(p.eps - 0.05) < 1e-9
+    assert back.tobytes() == b.tobytes()
+
+
+def test_dump_errors(tmp_path):
+    lib = nb.load()
+    bad = tmp_path / "bad.nbd"
+    bad.write_bytes(b"NOTNBODY" + b"\0" * 56)
+    n, fr = C.c_size_t(), C.c_uint64()
+    assert lib.nb_read_header(str(bad).encode(), C.byref(n), C.byref(fr), None) == L.NB_EFORMAT
+    assert b"magic" in lib.nb_last_error()
+    assert lib.nb_read_header(str(tmp_path / "missing").encode(), C.byref(n), C.byref(fr), None) == L.NB_EIO
+    short = tmp_path / "short.nbd"
+    b = nb.plummer_2d(10, 1)
+    nb.write_bodies(short, b)
+    short.write_bytes(short.read_bytes()[:-100])
+    out = nb.bodies_array(10)
+    assert lib.nb_read_bodies(str(short).encode(), out.ctypes.data, 10) == L.NB_EFORMAT
+    assert lib.nb_read_bodies(str(short).encode(), out.ctypes.data, 11) == L.NB_EINVAL
+
+
+def test_create_argument_validation():
+    lib = nb.load()
+    b = nb.plummer_2d(16, 1)
+    p = L.default_params()
+    assert not lib.nb_create(None, 16, C.byref(p)) and b"no bodies" in lib.nb_last_error()
+    p.struct_size = 4
+    assert not lib.nb_create(b.ctypes.data, 16, C.byref(p)) and b"struct_size" in lib.nb_last_error()
+    p = L.default_params(); p.precision = 7
+    assert not lib.nb_create(b.ctypes.data, 16, C.byref(p))
+    p = L.default_params(); p.i_begin, p.i_count = 10, 10
+    assert not lib.nb_create(b.ctypes.data, 16, C.byref(p)) and b"exceeds" in lib.nb_last_error()
+    p = L.default_params(); p.precision, p.rsqrt_mode = L.NB_FP64, L.NB_RSQRT_QUAKE
+    assert not lib.nb_create(b.ctypes.data, 16, C.byref(p))
+    with pytest.raises(TypeError):
+        nb.Simulation(np.zeros(4, np.float32))
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the product must refuse, not compute on the CPU."""
+    lib = nb.load()
+    if lib.nb_device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    with pytest.raises(nb.NBodyError) as e:
+        nb.Simulation(nb.plummer_2d(64, 1))
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_does_not_reference_oracle():
+    """The product path may not import, link or call anything under oracle/."""
+    for p in list((ROOT / "nbodysim_amd").rglob("*.py")) + list((ROOT / "nbodysim_amd" / "csrc").glob("*")) + \
+            list((ROOT / "nbodysim_amd" / "host").glob("*")):
+        if p.is_file() and p.suffix in {".py", ".c", ".h", ".hip", ".cpp", ".hpp", ""}:
+            txt = p.read_text(errors="ignore")
+            assert "nb_oracle" not in txt and "import nbo" not in txt and "libnbref" not in txt, p
+    out = subprocess.run(["ldd", str(L.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "oracle" not in out

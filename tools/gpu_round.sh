@@ -1,0 +1,37 @@
+#!/bin/bash
+# tools/gpu_round.sh — what one gpurun call runs: GPU tests, smoke, bench, (optional) profile.
+# Ordinary failures continue to the next stage; a stage killed by its timeout stops the run
+# (a hung GPU must not be poked again).
+set -u
+mkdir -p gpurun_out
+stage() {  # stage <seconds> <logfile> <cmd...>
+    local secs=$1 log=$2; shift 2
+    echo "=== $* (limit ${secs}s)" | tee -a gpurun_out/round.log
+    timeout -k 10 "$secs" "$@" > "$log" 2>&1
+    local rc=$?
+    echo "=== rc=$rc $log" | tee -a gpurun_out/round.log
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "stage timed out: stopping" | tee -a gpurun_out/round.log; tail -20 "$log"; exit $rc; fi
+    return $rc
+}
+: > gpurun_out/round.log
+for what in "$@"; do
+  case $what in
+    tests)  stage 900 gpurun_out/test_gpu.log python -m pytest tests -m gpu -x -q --durations=8; tail -15 gpurun_out/test_gpu.log ;;
+    smoke)  stage 300 gpurun_out/smoke.log python -c "import __graft_entry__ as g; g.smoke()"; tail -3 gpurun_out/smoke.log ;;
+    bench)  stage 600 gpurun_out/bench.log python bench.py --steps 20 --warmup 3; tail -2 gpurun_out/bench.log ;;
+    benchq) stage 300 gpurun_out/bench.log python bench.py --steps 20 --warmup 3 --no-cpu-baseline; tail -2 gpurun_out/bench.log ;;
+    cmain)  stage 300 gpurun_out/cmain.log ./build/nbody_main -n 262144 -s 20; tail -5 gpurun_out/cmain.log ;;
+    prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+            stage 600 gpurun_out/rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+            tail -3 gpurun_out/rocprof_stats.log; find gpurun_out/prof -name '*stats*' | head ;;
+    pmc)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+            for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
+                       "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS" \
+                       "GRBM_GUI_ACTIVE GRBM_COUNT FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+              tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+              stage 300 gpurun_out/pmc_$tag.log rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events
+            done
+            find gpurun_out/pmc -name '*counter_collection.csv' | head ;;
+    *) echo "unknown stage $what" ;;
+  esac
+done
