@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tools/summarize_profile.py — turn the rocprofv3 outputs merged back under gpurun_out/
+into the small, committed summaries under profiles/.
+
+    python tools/summarize_profile.py r01
+
+Reads  gpurun_out/prof/**/_kernel_stats.csv     (rocprofv3 --kernel-trace --stats)
+       gpurun_out/pmc/*/**/_counter_collection.csv  (separate --pmc passes)
+Writes profiles/<round>_kernel_stats.csv, profiles/<round>_pmc_summary.json and
+       profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB-units of
+1024 B... (rocprofv3 reports them in kilobytes); on gfx950 FETCH_SIZE under-reports wide
+coalesced reads by 2x, so reads are doubled; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = ROOT / "profiles"
+out.mkdir(exist_ok=True)
+
+stats = sorted(glob.glob(str(ROOT / "gpurun_out/prof/**/*_kernel_stats.csv"), recursive=True))
+if stats:
+    shutil.copy(stats[-1], out / f"{tag}_kernel_stats.csv")
+    print("kernel stats ->", out / f"{tag}_kernel_stats.csv")
+
+summary = {}
+meta = {}
+for f in sorted(glob.glob(str(ROOT / "gpurun_out/pmc/*/**/*counter_collection.csv"), recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta.setdefault(k, {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size") if x in r})
+    for k, d in agg.items():
+        for c, v in d.items():
+            summary.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+
+derived = {}
+for k, d in summary.items():
+    g = lambda c: d.get(c, {}).get("mean_per_launch")
+    x = {}
+    if g("GRBM_GUI_ACTIVE"):
+        x["gpu_cycles_per_xcd"] = g("GRBM_GUI_ACTIVE") / 8
+    if g("SQ_INSTS_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        x["valu_cycles_per_inst"] = 4 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU")
+        if g("GRBM_GUI_ACTIVE"):
+            x["valu_busy_frac"] = 4 * g("SQ_ACTIVE_INST_VALU") / 1024 / (g("GRBM_GUI_ACTIVE") / 8)
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+        x["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("FETCH_SIZE") is not None:
+        x["hbm_read_bytes_raw"] = g("FETCH_SIZE") * 1024
+        x["hbm_read_bytes_corrected"] = 2 * g("FETCH_SIZE") * 1024
+    if g("WRITE_SIZE") is not None:
+        x["hbm_write_bytes"] = g("WRITE_SIZE") * 1024
+    derived[k] = x
+
+(out / f"{tag}_pmc_summary.json").write_text(json.dumps({"counters": summary, "derived": derived, "dispatch": meta}, indent=1) + "\n")
+print("pmc summary ->", out / f"{tag}_pmc_summary.json")
+for k, x in derived.items():
+    if "force_tiled_f32" in k and "hbm_read_bytes_corrected" in x and "hbm_write_bytes" in x:
+        t = {"round": tag, "kernel": k, "force_kernel_hbm_bytes_per_launch": x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"],
+             "read_bytes_raw_FETCH_SIZE": x["hbm_read_bytes_raw"], "read_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
+             "write_bytes_WRITE_SIZE": x["hbm_write_bytes"]}
+        (out / "hbm_traffic.json").write_text(json.dumps(t, indent=1) + "\n")
+        print("hbm traffic ->", t)
