@@ -105,6 +105,8 @@ struct nb_sim {
     float pending_dt = 0.f;
     bool in_step = false;
     bool acc_valid = false;         // KDK: acc holds a(x_cur)
+    bool uniform_mass = false;      // every body has the same mass: the per-pair mass multiply is hoisted
+    float um_mass = 0.f;
 
     // profiling
     bool prof = false;
@@ -196,6 +198,12 @@ static void free_all(nb_sim *s)
 
 static int do_upload(nb_sim *s, const nb_body *in)
 {
+    // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
+    // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_NO_UNIFORM_MASS=1 disables it.
+    s->uniform_mass = s->n > 0 && !getenv("NB_NO_UNIFORM_MASS") && !s->fp64 && s->p.sum_order == NB_SUM_TILED;
+    for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
+        if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
+    s->um_mass = in[0].mass;
     HIPCHK(hipMemcpyAsync(s->aos_dev, in, s->n * sizeof(nb_body), hipMemcpyHostToDevice, s->stream));
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
@@ -343,9 +351,17 @@ static void launch_tiled_f32(nb_sim *s, const ForceJob &j, float eps2)
     const uint32_t i_tiles = j.i_tiles;
     const uint32_t grid = grid_blocks(i_tiles, j.js);
     float2 *out = (float2 *)s->partial + (size_t)j.slab0 * s->i_count;
-    force_tiled_f32<P, RSQ, GUARD, 8><<<grid, BLOCK, 0, s->stream>>>(
+    if constexpr (!GUARD) {
+        if (s->uniform_mass) {
+            force_tiled_f32<P, RSQ, false, 8, true><<<grid, BLOCK, 0, s->stream>>>(
+                (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+                (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, s->um_mass);
+            return;
+        }
+    }
+    force_tiled_f32<P, RSQ, GUARD, 8, false><<<grid, BLOCK, 0, s->stream>>>(
         (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
-        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2);
+        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f);
 }
 
 template <int P, bool GUARD>
@@ -638,11 +654,12 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u before=%d/%u after=%d/%u | CUs=%d",
+             "two-phase P/slices local=%d/%u before=%d/%u after=%d/%u | uniform_mass=%d | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
-             s->job_local.P, s->job_local.js, s->job_before.P, s->job_before.js, s->job_after.P, s->job_after.js, s->cus);
+             s->job_local.P, s->job_local.js, s->job_before.P, s->job_before.js, s->job_after.P, s->job_after.js,
+             (int)s->uniform_mass, s->cus);
     return NB_OK;
 }

@@ -31,6 +31,11 @@ constexpr int TJ = 256;     // j-particles per LDS tile (one per thread per stag
 
 enum { RSQ_EXACT = 0, RSQ_QUAKE = 1 };
 
+// Coordinates given to the padding lanes of a partial j-tile.  With mass 0 they contribute
+// nothing in the general path; in the uniform-mass path (no per-pair mass multiply) they sit
+// so far away that 1/r^3 = (7e-19)^3 underflows to exactly 0 while r^2 = 2e36 stays finite.
+constexpr float PAD_XY = 1.0e18f;
+
 // ---------------------------------------------------------------------------
 // Block -> (i_tile, j_slice) decode.  Workgroups are dealt round-robin over the
 // 8 XCDs (b % 8 shares an XCD, MI355X_MICROARCH §Workgroup dispatch): slices
@@ -90,13 +95,13 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 //   j_begin/j_end     the j range of this launch, cut into js slices
 // Lane t of tile T owns particles  i_begin + T*IT + p*512 + 2t + {0,1},  p < P.
 // ---------------------------------------------------------------------------
-template <int P, int RSQ, bool GUARD, int UNROLL>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false>
 __device__ __forceinline__
 void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
                           float2 *__restrict__ partial,
                           uint32_t i_begin, uint32_t i_count,
                           uint32_t j_begin, uint32_t j_end,
-                          uint32_t js, uint32_t i_tiles, float eps2)
+                          uint32_t js, uint32_t i_tiles, float eps2, float um_mass = 1.0f)
 {
     constexpr uint32_t IT = BLOCK * 2 * P;
     __shared__ v4f tile[2][TJ];
@@ -130,7 +135,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     // stage tile 0
     {
         const uint32_t j = s0 + t;
-        float2 pj = make_float2(0.f, 0.f);
+        float2 pj = make_float2(PAD_XY, PAD_XY);
         float mj = 0.f;
         if (j < s1) { pj = pos[j]; mj = mass[j]; }
         tile[0][t] = (v4f){pj.x, pj.y, mj, mj};
@@ -139,7 +144,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
 
     for (uint32_t it = 0; it < ntiles; ++it) {
         // prefetch the next tile into registers while this one is consumed
-        float2 pn = make_float2(0.f, 0.f);
+        float2 pn = make_float2(PAD_XY, PAD_XY);
         float mn = 0.f;
         const uint32_t jn1 = s0 + (it + 1) * TJ + t;
         if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }
@@ -172,7 +177,9 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                         inv = quake_rsqrt2(r2);
                 }
                 const v2f inv2 = inv * inv;
-                const v2f s = (mj * inv) * inv2;   // m / r^3
+                v2f s;
+                if constexpr (UM) s = inv * inv2;           // 1 / r^3, the common mass is applied once at the end
+                else s = (mj * inv) * inv2;                 // m / r^3
                 ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
                 ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
             }
@@ -184,6 +191,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     float2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
         if (li[p] + 1 < i_count) {
             *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
         } else if (li[p] < i_count) {
@@ -192,15 +200,15 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     }
 }
 
-template <int P, int RSQ, bool GUARD, int UNROLL>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false>
 __global__ __launch_bounds__(BLOCK)
 void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
                      float2 *__restrict__ partial,
                      uint32_t i_begin, uint32_t i_count,
                      uint32_t j_begin, uint32_t j_end,
-                     uint32_t js, uint32_t i_tiles, float eps2)
+                     uint32_t js, uint32_t i_tiles, float eps2, float um_mass)
 {
-    force_tiled_f32_body<P, RSQ, GUARD, UNROLL>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2);
+    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2, um_mass);
 }
 
 // ---------------------------------------------------------------------------

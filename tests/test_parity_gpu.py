@@ -174,6 +174,31 @@ def test_j_slices_and_lane_blocking_agree(nbo, js):
         assert max_rel(acc, ref) < 1e-4, (js, P)   # per-particle, one long fp32 running sum when js=1
 
 
+def test_uniform_mass_fast_path_matches_general_path(nbo):
+    """Equal masses select the kernel variant that hoists the per-pair mass multiply;
+    NB_NO_UNIFORM_MASS=1 forces the general variant.  Both must sit within 1e-5 of fp64."""
+    ic = nb.plummer_2d(5000, 17)          # ragged: exercises the far-away padding lanes too
+    d = nbo.step_f64(nbo.state_from_bodies(ic, np.float64), f32(0.03), f32(1e-3), 8)
+    pos64, vel64 = np.stack([d["x"], d["y"]], 1), np.stack([d["vx"], d["vy"]], 1)
+    out = {}
+    for tag, env in (("um", None), ("general", "1")):
+        if env:
+            os.environ["NB_NO_UNIFORM_MASS"] = env
+        try:
+            with nb.Simulation(ic, eps=0.03) as sim:
+                assert f"uniform_mass={0 if env else 1}" in sim.describe()
+                sim.advance(8, 1e-3)
+                out[tag] = sim.sync()
+        finally:
+            os.environ.pop("NB_NO_UNIFORM_MASS", None)
+        assert max_rel(out[tag]["pos"], pos64) < TOL and max_rel(out[tag]["vel"], vel64) < TOL, tag
+    assert max_rel(out["um"]["pos"], out["general"]["pos"]) < 2e-6
+    # unequal masses never take the fast path
+    b = random_bodies(600, 1)
+    with nb.Simulation(b, eps=0.1) as sim:
+        assert "uniform_mass=0" in sim.describe()
+
+
 # ------------------------------------------------------------------- fp64 ---
 def test_fp64_matches_fp64_direct(gold, nbo):
     flat = gold["ic_plummer_1024"]
