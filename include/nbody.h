@@ -191,7 +191,8 @@ int nb_read_bodies(const char *path, nb_body *out, size_t n);
  *
  *   nb_step_begin(s, dt)   enqueue: force from the OWNED j-block (already resident)
  *   ... host runs the all-gather into nb_pos_buffer(s, NB_POS_CURRENT) on its comm stream ...
- *   nb_step_finish(s)      enqueue: force from the remote j-blocks, kick, drift;
+ *   nb_step_finish(s)      enqueue: force from the remote j-blocks (one launch over
+ *                          "everything but my block"), kick, drift;
  *                          new owned positions land in the NEXT replica, which
  *                          becomes CURRENT.
  * Stream ordering between the two calls and the collective is the caller's

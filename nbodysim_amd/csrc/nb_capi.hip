@@ -72,7 +72,8 @@ extern "C" void nb_params_default(nb_params *p)
 // ---------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------
-struct ForceJob { uint32_t j_begin, j_end, js, slab0; int P; uint32_t i_tiles; };
+// j_begin/j_end are virtual indices that skip [gap_begin, gap_begin + gap_len)
+struct ForceJob { uint32_t j_begin, j_end, js, slab0; int P; uint32_t i_tiles; uint32_t gap_begin, gap_len; };
 
 struct nb_sim {
     nb_params p;
@@ -98,7 +99,7 @@ struct nb_sim {
     size_t ered_blocks = 0;
 
     // launch geometry (per job: particles per lane and j-slices)
-    ForceJob job_all{}, job_local{}, job_before{}, job_after{};
+    ForceJob job_all{}, job_local{}, job_remote{};
     uint32_t slabs_all = 0, slabs_two_phase = 0;
 
     uint64_t frame = 0;
@@ -130,42 +131,46 @@ static int bind(const nb_sim *s)
 // workgroups per CU.  When i-particles are scarce (sharded or small runs) the
 // j range is cut into more slices, and P drops only when the slices would get
 // shorter than two LDS tiles.
-static uint32_t legal_slices(uint32_t js)
+// Slices are whole LDS tiles and none is empty: js = ceil(tiles / ceil(tiles / want)).
+static uint32_t even_slices(uint32_t jn, uint32_t want)
 {
-    // decode_block handles 1, 2, 4 or a multiple of 8
-    if (js >= 8) return (js / 8) * 8;
-    if (js >= 4) return 4;
-    if (js >= 2) return 2;
-    return 1;
+    const uint32_t tiles = (jn + TJ - 1) / TJ;
+    if (want < 1) want = 1;
+    if (want > tiles) want = tiles;
+    const uint32_t per = (tiles + want - 1) / want;
+    return (tiles + per - 1) / per;
 }
 
-static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t slab0)
+static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t slab0,
+                         uint32_t gap_begin = 0xffffffffu, uint32_t gap_len = 0)
 {
-    ForceJob j{jb, je, 0, slab0, 1, 0};
+    ForceJob j{jb, je, 0, slab0, 1, 0, gap_begin, gap_len};
     const uint32_t ic = (uint32_t)s->i_count;
     if (je <= jb) return j;
     const uint32_t jn = je - jb;
     if (s->p.sum_order == NB_SUM_SEQUENTIAL) { j.js = 1; j.P = 1; j.i_tiles = (ic + BLOCK - 1) / BLOCK; return j; }
     const uint32_t lanes_i = s->fp64 ? 1u : 2u;                 // particles per lane per P
-    const uint32_t target = 16u * (uint32_t)s->cus;             // workgroups
-    const uint32_t max_js = jn / TJ ? jn / TJ : 1;              // >= one full tile per slice
+    const uint32_t target = 16u * (uint32_t)s->cus;             // workgroups wanted in the grid
+    const uint32_t max_slices = 128;                            // bounds the slab traffic of `integrate`
+    const uint32_t tiles = (jn + TJ - 1) / TJ;
     const char *envp = getenv("NB_FORCE_P");
     const int forced_p = envp ? atoi(envp) : 0;
     const int pmax = s->fp64 ? 2 : 4;
-    int best_p = 1; uint32_t best_js = 1;
+    // Largest P (most independent chains per lane, fewest LDS reads per pair) that still yields
+    // at least half the wanted workgroups; P halves only when both i and j are scarce.
     for (int P = pmax; P >= 1; P >>= 1) {
-        if (forced_p > 0 && P != forced_p && !(forced_p > pmax && P == pmax)) continue;
+        if (forced_p > 0 && P != (forced_p > pmax ? pmax : forced_p)) continue;
         const uint32_t i_tiles = (ic + BLOCK * lanes_i * P - 1) / (BLOCK * lanes_i * P);
         uint32_t want = (target + i_tiles - 1) / i_tiles;
+        if (want > max_slices) want = max_slices;
         if (s->p.j_slices > 0) want = (uint32_t)s->p.j_slices;
-        uint32_t js = legal_slices(want < 1 ? 1 : want);
-        const uint32_t cap = legal_slices(max_js >= 2 && forced_p == 0 && s->p.j_slices <= 0 ? max_js / 2 : max_js);
-        best_p = P; best_js = js > cap ? cap : js;
-        if (js <= cap || forced_p > 0) break;                   // enough slices at this P
+        j.P = P;
+        j.i_tiles = i_tiles;
+        j.js = even_slices(jn, want);
+        if (forced_p > 0 || s->p.j_slices > 0 || P == 1) break;
+        const uint32_t reach = i_tiles * (tiles < max_slices ? tiles : max_slices);   // most workgroups this P can give
+        if (reach >= target / 2) break;
     }
-    j.P = best_p;
-    j.js = best_js;
-    j.i_tiles = (ic + BLOCK * lanes_i * j.P - 1) / (BLOCK * lanes_i * j.P);
     return j;
 }
 
@@ -175,9 +180,9 @@ static void plan(nb_sim *s)
     s->job_all = plan_job(s, 0, n, 0);
     s->slabs_all = s->job_all.js;
     s->job_local = plan_job(s, ib, ib + ic, 0);
-    s->job_before = plan_job(s, 0, ib, s->job_local.js);
-    s->job_after = plan_job(s, ib + ic, n, s->job_local.js + s->job_before.js);
-    s->slabs_two_phase = s->job_local.js + s->job_before.js + s->job_after.js;
+    // everything but the owned block, in one launch: virtual j range [0, n - ic) with a gap at the block
+    s->job_remote = plan_job(s, 0, n - ic, s->job_local.js, ib, ic);
+    s->slabs_two_phase = s->job_local.js + s->job_remote.js;
 }
 
 static void free_all(nb_sim *s)
@@ -355,13 +360,14 @@ static void launch_tiled_f32(nb_sim *s, const ForceJob &j, float eps2)
         if (s->uniform_mass) {
             force_tiled_f32<P, RSQ, false, 8, true><<<grid, BLOCK, 0, s->stream>>>(
                 (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
-                (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, s->um_mass);
+                (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, s->um_mass,
+                j.gap_begin, j.gap_len);
             return;
         }
     }
     force_tiled_f32<P, RSQ, GUARD, 8, false><<<grid, BLOCK, 0, s->stream>>>(
         (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
-        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f);
+        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f, j.gap_begin, j.gap_len);
 }
 
 template <int P, bool GUARD>
@@ -372,7 +378,7 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
     double2 *out = (double2 *)s->partial + (size_t)j.slab0 * s->i_count;
     force_tiled_f64<P, GUARD, 4><<<grid, BLOCK, 0, s->stream>>>(
         (const double2 *)s->pos[s->cur], (const double *)s->mass, out,
-        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2);
+        (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, j.gap_begin, j.gap_len);
 }
 
 static int launch_force(nb_sim *s, const ForceJob &j)
@@ -464,8 +470,7 @@ extern "C" int nb_step_finish(nb_sim *s)
     int rc;
     uint32_t nslabs;
     if (two_phase(s)) {
-        if ((rc = launch_force(s, s->job_before))) return rc;
-        if ((rc = launch_force(s, s->job_after))) return rc;
+        if ((rc = launch_force(s, s->job_remote))) return rc;
         nslabs = s->slabs_two_phase;
     } else {
         if ((rc = launch_force(s, s->job_all))) return rc;
@@ -654,12 +659,11 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u before=%d/%u after=%d/%u | uniform_mass=%d | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
-             s->job_local.P, s->job_local.js, s->job_before.P, s->job_before.js, s->job_after.P, s->job_after.js,
-             (int)s->uniform_mass, s->cus);
+             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, s->cus);
     return NB_OK;
 }

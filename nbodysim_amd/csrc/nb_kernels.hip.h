@@ -44,28 +44,34 @@ constexpr float PAD_XY = 1.0e18f;
 // ---------------------------------------------------------------------------
 struct TileMap { uint32_t i_tile, slice; bool valid; };
 
+// Any js >= 1.  Slices are dealt in groups of 8 (one per XCD): with g = ceil(js/8) groups a
+// workgroup b serves slice (b%8) + 8*((b/8) % g) of i-tile (b/8)/g; for js < 8 the eight XCD
+// lanes are shared between 8/js' i-tiles (js' = js rounded up to 1, 2, 4).  Combinations that
+// fall outside (slice >= js or i_tile >= i_tiles) are empty workgroups that exit at once.
+__host__ __device__ __forceinline__ uint32_t small_js(uint32_t js) { return js <= 1 ? 1u : js <= 2 ? 2u : 4u; }
+
 __device__ __forceinline__ TileMap decode_block(uint32_t b, uint32_t i_tiles, uint32_t js)
 {
     TileMap m;
     const uint32_t xcd = b & 7u, k = b >> 3;
-    if (js >= 8u) {                 // js is a multiple of 8 (host guarantees)
-        const uint32_t g = js >> 3;
+    if (js > 4u) {
+        const uint32_t g = (js + 7u) >> 3;
         m.slice = xcd + 8u * (k % g);
         m.i_tile = k / g;
-    } else {                        // js in {1,2,4}
-        const uint32_t per = 8u / js;
-        m.slice = xcd % js;
-        m.i_tile = k * per + xcd / js;
+    } else {
+        const uint32_t jr = small_js(js), per = 8u / jr;
+        m.slice = xcd % jr;
+        m.i_tile = k * per + xcd / jr;
     }
-    m.valid = m.i_tile < i_tiles;
+    m.valid = m.i_tile < i_tiles && m.slice < js;
     return m;
 }
 
 // grid size matching decode_block
 static inline uint32_t grid_blocks(uint32_t i_tiles, uint32_t js)
 {
-    if (js >= 8u) return i_tiles * js;
-    const uint32_t per = 8u / js;
+    if (js > 4u) return i_tiles * ((js + 7u) / 8u) * 8u;
+    const uint32_t per = 8u / small_js(js);
     return ((i_tiles + per - 1) / per) * 8u;
 }
 
@@ -92,7 +98,9 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 //   mass     full n
 //   partial  [js][i_count] partial accelerations of this launch's slabs
 //   i_begin/i_count   the owned block (particles this GPU integrates)
-//   j_begin/j_end     the j range of this launch, cut into js slices
+//   j_begin/j_end     the j range of this launch, cut into js slices; the range is in
+//                     VIRTUAL indices that skip [gap_begin, gap_begin+gap_len): a sharded
+//                     rank sweeps "everything but my own block" in one launch
 // Lane t of tile T owns particles  i_begin + T*IT + p*512 + 2t + {0,1},  p < P.
 // ---------------------------------------------------------------------------
 template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false>
@@ -101,7 +109,8 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                           float2 *__restrict__ partial,
                           uint32_t i_begin, uint32_t i_count,
                           uint32_t j_begin, uint32_t j_end,
-                          uint32_t js, uint32_t i_tiles, float eps2, float um_mass = 1.0f)
+                          uint32_t js, uint32_t i_tiles, float eps2, float um_mass = 1.0f,
+                          uint32_t gap_begin = 0xffffffffu, uint32_t gap_len = 0)
 {
     constexpr uint32_t IT = BLOCK * 2 * P;
     __shared__ v4f tile[2][TJ];
@@ -137,7 +146,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
         const uint32_t j = s0 + t;
         float2 pj = make_float2(PAD_XY, PAD_XY);
         float mj = 0.f;
-        if (j < s1) { pj = pos[j]; mj = mass[j]; }
+        if (j < s1) { const uint32_t jg = j + (j >= gap_begin ? gap_len : 0u); pj = pos[jg]; mj = mass[jg]; }
         tile[0][t] = (v4f){pj.x, pj.y, mj, mj};
     }
     __syncthreads();
@@ -147,7 +156,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
         float2 pn = make_float2(PAD_XY, PAD_XY);
         float mn = 0.f;
         const uint32_t jn1 = s0 + (it + 1) * TJ + t;
-        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }
+        if (jn1 < s1) { const uint32_t jg = jn1 + (jn1 >= gap_begin ? gap_len : 0u); pn = pos[jg]; mn = mass[jg]; }
 
         const v4f *__restrict__ cur = tile[it & 1];
 #pragma unroll UNROLL
@@ -206,9 +215,11 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
                      float2 *__restrict__ partial,
                      uint32_t i_begin, uint32_t i_count,
                      uint32_t j_begin, uint32_t j_end,
-                     uint32_t js, uint32_t i_tiles, float eps2, float um_mass)
+                     uint32_t js, uint32_t i_tiles, float eps2, float um_mass,
+                     uint32_t gap_begin, uint32_t gap_len)
 {
-    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2, um_mass);
+    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2, um_mass,
+                                                    gap_begin, gap_len);
 }
 
 // ---------------------------------------------------------------------------
@@ -398,7 +409,8 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
                      double2 *__restrict__ partial,
                      uint32_t i_begin, uint32_t i_count,
                      uint32_t j_begin, uint32_t j_end,
-                     uint32_t js, uint32_t i_tiles, double eps2)
+                     uint32_t js, uint32_t i_tiles, double eps2,
+                     uint32_t gap_begin, uint32_t gap_len)
 {
     constexpr uint32_t IT = BLOCK * P;
     struct alignas(16) JD { double x, y, m, pad; };
@@ -424,14 +436,14 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
     {
         const uint32_t j = s0 + t;
         double2 pj = make_double2(0.0, 0.0); double mj = 0.0;
-        if (j < s1) { pj = pos[j]; mj = mass[j]; }
+        if (j < s1) { const uint32_t jg = j + (j >= gap_begin ? gap_len : 0u); pj = pos[jg]; mj = mass[jg]; }
         tile[0][t] = JD{pj.x, pj.y, mj, 0.0};
     }
     __syncthreads();
     for (uint32_t it = 0; it < ntiles; ++it) {
         double2 pn = make_double2(0.0, 0.0); double mn = 0.0;
         const uint32_t jn1 = s0 + (it + 1) * TJ + t;
-        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }
+        if (jn1 < s1) { const uint32_t jg = jn1 + (jn1 >= gap_begin ? gap_len : 0u); pn = pos[jg]; mn = mass[jg]; }
         const JD *__restrict__ cur = tile[it & 1];
 #pragma unroll UNROLL
         for (int jj = 0; jj < TJ; ++jj) {

@@ -154,11 +154,16 @@ def test_tiled_eps0_guard(nbo, rsqrt):
     with nb.Simulation(b, eps=0.0, rsqrt=rsqrt) as sim:
         acc = sim.accelerations()
     assert np.isfinite(acc).all()
-    ax, ay = nbo.accel_f32(nbo.state_from_bodies(b), 0.0, nbo.RSQRT_QUAKE if rsqrt == "quake" else nbo.RSQRT_EXACT)
-    assert max_rel(acc, np.stack([ax, ay], 1)) < 5e-5
+    ax, ay = nbo.accel_f64(nbo.state_from_bodies(b, np.float64), 0.0)
+    a64 = np.stack([ax, ay], 1)
+    if rsqrt == "quake":   # Quake forces are ~0.3 % weak by construction: compare with the f32 restatement
+        ax, ay = nbo.accel_f32(nbo.state_from_bodies(b), 0.0, nbo.RSQRT_QUAKE)
+        a64 = np.stack([ax, ay], 1).astype(np.float64)
+    # eps = 0 lets near-coincident pairs produce huge, cancelling terms: judge on the global force scale
+    assert np.max(np.abs(acc - a64)) < 1e-5 * np.max(np.abs(a64))
 
 
-@pytest.mark.parametrize("js", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("js", [1, 2, 3, 4, 8, 11, 16, 32])
 def test_j_slices_and_lane_blocking_agree(nbo, js):
     ic = nb.plummer_2d(8192, 9)
     ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), 0.02)

@@ -49,7 +49,7 @@ static float time_once(const Ctx &c, uint32_t js, size_t dyn_lds)
     const uint32_t grid = grid_blocks(i_tiles, js);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, c.stream));
-    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n);
+    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n, 0xffffffffu, 0u);
     CK(hipEventRecord(e1, c.stream));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
