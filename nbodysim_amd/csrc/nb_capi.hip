@@ -75,6 +75,8 @@ extern "C" void nb_params_default(nb_params *p)
 // j_begin/j_end are virtual indices that skip [gap_begin, gap_begin + gap_len)
 struct ForceJob { uint32_t j_begin, j_end, js, slab0; int P; uint32_t i_tiles; uint32_t gap_begin, gap_len; };
 
+constexpr int F32_WS = 4;   // waves of a workgroup sharing one i-set in force_tiled_f32 (in-workgroup j-split)
+
 struct nb_sim {
     nb_params p;
     size_t n = 0, i_begin = 0, i_count = 0;
@@ -149,8 +151,11 @@ static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t sla
     if (je <= jb) return j;
     const uint32_t jn = je - jb;
     if (s->p.sum_order == NB_SUM_SEQUENTIAL) { j.js = 1; j.P = 1; j.i_tiles = (ic + BLOCK - 1) / BLOCK; return j; }
+    // fp32: the 4 waves of a workgroup share 64 i-lanes and split each j-tile (WS = 4), a lane owns 2P
+    // particles -> 128P particles per workgroup; fp64: 256 i-lanes, P particles per lane.
     const uint32_t lanes_i = s->fp64 ? 1u : 2u;                 // particles per lane per P
-    const uint32_t target = 16u * (uint32_t)s->cus;             // workgroups wanted in the grid
+    const uint32_t ilanes = s->fp64 ? (uint32_t)BLOCK : (uint32_t)BLOCK / F32_WS;
+    const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (tools/force_bench.hip sweep)
     const uint32_t max_slices = 128;                            // bounds the slab traffic of `integrate`
     const uint32_t tiles = (jn + TJ - 1) / TJ;
     const char *envp = getenv("NB_FORCE_P");
@@ -160,7 +165,7 @@ static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t sla
     // at least half the wanted workgroups; P halves only when both i and j are scarce.
     for (int P = pmax; P >= 1; P >>= 1) {
         if (forced_p > 0 && P != (forced_p > pmax ? pmax : forced_p)) continue;
-        const uint32_t i_tiles = (ic + BLOCK * lanes_i * P - 1) / (BLOCK * lanes_i * P);
+        const uint32_t i_tiles = (ic + ilanes * lanes_i * P - 1) / (ilanes * lanes_i * P);
         uint32_t want = (target + i_tiles - 1) / i_tiles;
         if (want > max_slices) want = max_slices;
         if (s->p.j_slices > 0) want = (uint32_t)s->p.j_slices;
@@ -358,14 +363,14 @@ static void launch_tiled_f32(nb_sim *s, const ForceJob &j, float eps2)
     float2 *out = (float2 *)s->partial + (size_t)j.slab0 * s->i_count;
     if constexpr (!GUARD) {
         if (s->uniform_mass) {
-            force_tiled_f32<P, RSQ, false, 8, true><<<grid, BLOCK, 0, s->stream>>>(
+            force_tiled_f32<P, RSQ, false, 8, true, F32_WS><<<grid, BLOCK, 0, s->stream>>>(
                 (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
                 (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, s->um_mass,
                 j.gap_begin, j.gap_len);
             return;
         }
     }
-    force_tiled_f32<P, RSQ, GUARD, 8, false><<<grid, BLOCK, 0, s->stream>>>(
+    force_tiled_f32<P, RSQ, GUARD, 8, false, F32_WS><<<grid, BLOCK, 0, s->stream>>>(
         (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
         (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f, j.gap_begin, j.gap_len);
 }
@@ -658,11 +663,11 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const ForceJob &a = s->job_all;
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
-             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
+             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
              "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
-             BLOCK, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
+             BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, s->cus);
     return NB_OK;

@@ -101,9 +101,19 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 //   j_begin/j_end     the j range of this launch, cut into js slices; the range is in
 //                     VIRTUAL indices that skip [gap_begin, gap_begin+gap_len): a sharded
 //                     rank sweeps "everything but my own block" in one launch
-// Lane t of tile T owns particles  i_begin + T*IT + p*512 + 2t + {0,1},  p < P.
+// WS = how many of the workgroup's 4 waves share one set of i-particles and split each
+// j-tile between them (in-workgroup j-split):
+//   WS = 1  every wave owns its own i's (256 i-lanes), each wave walks the whole tile;
+//   WS = 4  the 4 waves own the SAME 64 i-lanes and walk one quarter of the tile each;
+//           their partial sums are combined through LDS in wave order at the end
+//           (deterministic), so the workgroup still writes ONE slab row per particle.
+//           Four times the workgroups for the same number of slabs: this is what keeps
+//           256 CUs busy when i-particles are scarce (small N, sharded ranks) without
+//           multiplying the slab traffic.
+// Lane l (of i-lane group) of tile T owns particles
+//   i_begin + T*IT + p*(2*LANES_I) + 2l + {0,1},  p < P,  IT = LANES_I*2P,  LANES_I = 256/WS.
 // ---------------------------------------------------------------------------
-template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1>
 __device__ __forceinline__
 void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
                           float2 *__restrict__ partial,
@@ -112,12 +122,20 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                           uint32_t js, uint32_t i_tiles, float eps2, float um_mass = 1.0f,
                           uint32_t gap_begin = 0xffffffffu, uint32_t gap_len = 0)
 {
-    constexpr uint32_t IT = BLOCK * 2 * P;
-    __shared__ v4f tile[2][TJ];
+    static_assert(WS == 1 || WS == 2 || WS == 4, "WS waves share an i-set");
+    constexpr uint32_t LANES_I = BLOCK / WS;          // distinct i-lanes in the workgroup
+    constexpr uint32_t IT = LANES_I * 2 * P;          // particles per workgroup
+    constexpr uint32_t JW = TJ / WS;                  // j's of a tile walked by one wave group
+    constexpr uint32_t RED = (WS - 1) * P * LANES_I;  // v4f slots of the final cross-wave reduction
+    constexpr uint32_t SMEM = 2 * TJ > RED ? 2 * TJ : RED;
+    __shared__ v4f smem[SMEM];
+    v4f (*tile)[TJ] = reinterpret_cast<v4f (*)[TJ]>(smem);
 
     const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
     if (!tm.valid) return;
     const uint32_t t = threadIdx.x;
+    const uint32_t lane_i = t % LANES_I;              // which i-lane
+    const uint32_t w = t / LANES_I;                   // which share of every tile (0 when WS == 1)
 
     // slice bounds, multiples of TJ from j_begin
     const uint32_t jn = j_end - j_begin;
@@ -130,7 +148,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     uint32_t li[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        li[p] = tm.i_tile * IT + (uint32_t)p * (BLOCK * 2) + 2u * t;
+        li[p] = tm.i_tile * IT + (uint32_t)p * (LANES_I * 2) + 2u * lane_i;
         const uint32_t l0 = min(li[p], i_count - 1), l1 = min(li[p] + 1, i_count - 1);
         const float2 p0 = pos[i_begin + l0], p1 = pos[i_begin + l1];
         xi[p] = (v2f){p0.x, p1.x};
@@ -158,9 +176,9 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
         const uint32_t jn1 = s0 + (it + 1) * TJ + t;
         if (jn1 < s1) { const uint32_t jg = jn1 + (jn1 >= gap_begin ? gap_len : 0u); pn = pos[jg]; mn = mass[jg]; }
 
-        const v4f *__restrict__ cur = tile[it & 1];
+        const v4f *__restrict__ cur = tile[it & 1] + w * JW;
 #pragma unroll UNROLL
-        for (int jj = 0; jj < TJ; ++jj) {
+        for (int jj = 0; jj < (int)JW; ++jj) {
             const v4f q = cur[jj];                 // broadcast ds_read_b128
             const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, mj = {q.z, q.w};
 #pragma unroll
@@ -197,6 +215,27 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
         __syncthreads();
     }
 
+    if constexpr (WS > 1) {
+        // combine the WS partial sums of each particle in wave-group order 0,1,..,WS-1
+        // (the tile buffers are free: the loop ended on a barrier)
+        if (w > 0) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                smem[((w - 1) * P + p) * LANES_I + lane_i] = (v4f){ax[p].x, ay[p].x, ax[p].y, ay[p].y};
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int k = 0; k < WS - 1; ++k) {
+                const v4f r = smem[(k * P + p) * LANES_I + lane_i];
+                ax[p] += (v2f){r.x, r.z};
+                ay[p] += (v2f){r.y, r.w};
+            }
+        }
+    }
+
     float2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -209,7 +248,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     }
 }
 
-template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1>
 __global__ __launch_bounds__(BLOCK)
 void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
                      float2 *__restrict__ partial,
@@ -218,119 +257,8 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
                      uint32_t js, uint32_t i_tiles, float eps2, float um_mass,
                      uint32_t gap_begin, uint32_t gap_len)
 {
-    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2, um_mass,
-                                                    gap_begin, gap_len);
-}
-
-// ---------------------------------------------------------------------------
-// force_wave_f32 — barrier-free variant of the fast path: ONE wave64 per
-// workgroup, each wave stages its own 64-particle j-chunks in a private 1 KiB
-// LDS tile (ds_write_b128 once per chunk, 64 broadcast ds_read_b128 back), so
-// there is no s_barrier anywhere and the 8 waves a SIMD can hold drift freely
-// and keep the VALU issuing (the kernel is VALU-bound: 9 packed ops at 4 cycles
-// + 2 v_rsq_f32 at 8 cycles per 128 pairs — DESIGN.md §roofline).
-// Same arithmetic, same slabs, same block decode as force_tiled_f32; a lane
-// owns 2P particles: i_begin + T*(128P) + p*128 + 2*lane + {0,1}.
-// ---------------------------------------------------------------------------
-constexpr int WAVE = 64;
-
-template <int P, int RSQ, bool GUARD, int UNROLL>
-__device__ __forceinline__
-void force_wave_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
-                         float2 *__restrict__ partial,
-                         uint32_t i_begin, uint32_t i_count,
-                         uint32_t j_begin, uint32_t j_end,
-                         uint32_t js, uint32_t i_tiles, float eps2)
-{
-    constexpr uint32_t IT = WAVE * 2 * P;
-    __shared__ v4f tile[WAVE];
-
-    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
-    if (!tm.valid) return;
-    const uint32_t t = threadIdx.x;
-
-    const uint32_t jn = j_end - j_begin;
-    const uint32_t slice_len = (((jn + js - 1) / js + WAVE - 1) / WAVE) * WAVE;
-    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
-    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
-
-    v2f xi[P], yi[P], ax[P], ay[P];
-    uint32_t li[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        li[p] = tm.i_tile * IT + (uint32_t)p * (WAVE * 2) + 2u * t;
-        const uint32_t l0 = min(li[p], i_count - 1), l1 = min(li[p] + 1, i_count - 1);
-        const float2 p0 = pos[i_begin + l0], p1 = pos[i_begin + l1];
-        xi[p] = (v2f){p0.x, p1.x};
-        yi[p] = (v2f){p0.y, p1.y};
-        ax[p] = (v2f){0.f, 0.f};
-        ay[p] = (v2f){0.f, 0.f};
-    }
-    const v2f e2 = {eps2, eps2};
-
-    const uint32_t nchunks = (s1 - s0 + WAVE - 1) / WAVE;
-    float2 pn = make_float2(0.f, 0.f);
-    float mn = 0.f;
-    if (s0 + t < s1) { pn = pos[s0 + t]; mn = mass[s0 + t]; }
-
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        tile[t] = (v4f){pn.x, pn.y, mn, mn};      // this wave's chunk c (same-wave LDS order: no barrier)
-        const uint32_t jn1 = s0 + (c + 1) * WAVE + t;
-        pn = make_float2(0.f, 0.f); mn = 0.f;
-        if (jn1 < s1) { pn = pos[jn1]; mn = mass[jn1]; }   // chunk c+1 in flight behind the compute
-#pragma unroll UNROLL
-        for (int jj = 0; jj < WAVE; ++jj) {
-            const v4f q = tile[jj];
-            const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, mj = {q.z, q.w};
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const v2f dx = xj - xi[p];
-                const v2f dy = yj - yi[p];
-                v2f r2, inv;
-                if constexpr (GUARD) {
-                    r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
-                    if constexpr (RSQ == RSQ_EXACT)
-                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-                    else
-                        inv = quake_rsqrt2(r2);
-                    inv.x = r2.x > 0.f ? inv.x : 0.f;
-                    inv.y = r2.y > 0.f ? inv.y : 0.f;
-                } else {
-                    r2 = __builtin_elementwise_fma(dx, dx, e2);
-                    r2 = __builtin_elementwise_fma(dy, dy, r2);
-                    if constexpr (RSQ == RSQ_EXACT)
-                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-                    else
-                        inv = quake_rsqrt2(r2);
-                }
-                const v2f inv2 = inv * inv;
-                const v2f s = (mj * inv) * inv2;
-                ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
-                ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
-            }
-        }
-    }
-
-    float2 *__restrict__ out = partial + (size_t)tm.slice * i_count;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (li[p] + 1 < i_count) {
-            *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
-        } else if (li[p] < i_count) {
-            out[li[p]] = make_float2(ax[p].x, ay[p].x);
-        }
-    }
-}
-
-template <int P, int RSQ, bool GUARD, int UNROLL>
-__global__ __launch_bounds__(WAVE)
-void force_wave_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
-                    float2 *__restrict__ partial,
-                    uint32_t i_begin, uint32_t i_count,
-                    uint32_t j_begin, uint32_t j_end,
-                    uint32_t js, uint32_t i_tiles, float eps2)
-{
-    force_wave_f32_body<P, RSQ, GUARD, UNROLL>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2);
+    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM, WS>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2,
+                                                        um_mass, gap_begin, gap_len);
 }
 
 // ---------------------------------------------------------------------------

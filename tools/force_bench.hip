@@ -42,14 +42,14 @@ void force_diag(const float2 *pos, const float *mass, float2 *partial, uint32_t 
 
 struct Ctx { float2 *pos; float *mass; float2 *partial; uint32_t n; float eps2; hipStream_t stream; };
 
-template <int P, int UNROLL, bool UMASS = false>
+template <int P, int UNROLL, bool UMASS = false, int WS = 1>
 static float time_once(const Ctx &c, uint32_t js, size_t dyn_lds)
 {
-    const uint32_t i_tiles = (c.n + BLOCK * 2 * P - 1) / (BLOCK * 2 * P);
+    const uint32_t i_tiles = (c.n + BLOCK / WS * 2 * P - 1) / (BLOCK / WS * 2 * P);
     const uint32_t grid = grid_blocks(i_tiles, js);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, c.stream));
-    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n, 0xffffffffu, 0u);
+    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS, WS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n, 0xffffffffu, 0u);
     CK(hipEventRecord(e1, c.stream));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -57,34 +57,16 @@ static float time_once(const Ctx &c, uint32_t js, size_t dyn_lds)
     return ms;
 }
 
-template <int P, int UNROLL>
-static float time_wave(const Ctx &c, uint32_t js)
-{
-    const uint32_t i_tiles = (c.n + WAVE * 2 * P - 1) / (WAVE * 2 * P);
-    const uint32_t grid = grid_blocks(i_tiles, js);
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipEventRecord(e0, c.stream));
-    force_wave_f32<P, RSQ_EXACT, false, UNROLL><<<grid, WAVE, 0, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2);
-    CK(hipEventRecord(e1, c.stream));
-    CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
-    return ms;
-}
-
-struct Cfg { int P, unroll; uint32_t js; size_t lds; bool wave = false; bool um = false; };
+struct Cfg { int P, unroll; uint32_t js; size_t lds; bool wave = false; bool um = false; int ws = 1; };
 
 static float run_cfg(const Ctx &c, const Cfg &f)
 {
-    if (f.wave) {
-        if (f.P == 1 && f.unroll == 8) return time_wave<1, 8>(c, f.js);
-        if (f.P == 2 && f.unroll == 8) return time_wave<2, 8>(c, f.js);
-        if (f.P == 2 && f.unroll == 4) return time_wave<2, 4>(c, f.js);
-        if (f.P == 2 && f.unroll == 16) return time_wave<2, 16>(c, f.js);
-        if (f.P == 3 && f.unroll == 4) return time_wave<3, 4>(c, f.js);
-        if (f.P == 4 && f.unroll == 4) return time_wave<4, 4>(c, f.js);
-        if (f.P == 4 && f.unroll == 8) return time_wave<4, 8>(c, f.js);
-        fprintf(stderr, "unsupported wave cfg\n"); exit(1);
+    if (f.ws == 4) {
+        if (f.um && f.P == 4) return time_once<4, 8, true, 4>(c, f.js, f.lds);
+        if (f.um && f.P == 2) return time_once<2, 8, true, 4>(c, f.js, f.lds);
+        if (!f.um && f.P == 4) return time_once<4, 8, false, 4>(c, f.js, f.lds);
+        if (!f.um && f.P == 2) return time_once<2, 8, false, 4>(c, f.js, f.lds);
+        fprintf(stderr, "unsupported ws cfg\n"); exit(1);
     }
     if (f.um) {
         if (f.P == 4 && f.unroll == 8) return time_once<4, 8, true>(c, f.js, f.lds);
@@ -159,12 +141,13 @@ int main(int argc, char **argv)
     CK(hipMemcpy(c.mass, hm.data(), n * sizeof(float), hipMemcpyHostToDevice));
 
     std::vector<Cfg> cfgs;
-    for (uint32_t js : {16u, 24u, 32u, 40u, 48u, 64u}) {
-        cfgs.push_back({4, 8, js, 0});
-        cfgs.push_back({4, 8, js, 0, false, true});
-        cfgs.push_back({4, 4, js, 0, false, true});
-        cfgs.push_back({2, 8, js, 0, false, true});
-        cfgs.push_back({2, 16, js, 0, false, true});
+    for (bool um : {true, false}) {
+        cfgs.push_back({4, 8, 32, 0, false, um, 1});
+        cfgs.push_back({4, 8, 64, 0, false, um, 1});
+        for (uint32_t js : {4u, 8u, 16u, 32u}) {
+            cfgs.push_back({4, 8, js, 0, false, um, 4});
+            cfgs.push_back({2, 8, js, 0, false, um, 4});
+        }
     }
     const int rounds = 5;
     std::vector<std::vector<float>> ms(cfgs.size());
@@ -175,10 +158,10 @@ int main(int argc, char **argv)
     for (size_t k = 0; k < cfgs.size(); ++k) {
         std::sort(ms[k].begin(), ms[k].end());
         const double med = ms[k][rounds / 2], mn = ms[k][0];
-        const uint32_t per = (cfgs[k].wave ? WAVE : BLOCK) * 2 * cfgs[k].P;
+        const uint32_t per = BLOCK / cfgs[k].ws * 2 * cfgs[k].P;
         const uint32_t i_tiles = (n + per - 1) / per;
-        printf("%s%s P=%d unroll=%2d js=%2u lds=%6zu grid=%5u : med %.3f ms  min %.3f ms  -> %.2f TFLOP/s (%.1f%% of 157.3)\n",
-               cfgs[k].wave ? "wave " : "block", cfgs[k].um ? " UM" : "   ", cfgs[k].P, cfgs[k].unroll, cfgs[k].js, cfgs[k].lds, grid_blocks(i_tiles, cfgs[k].js), med, mn,
+        printf("WS=%d%s P=%d unroll=%2d js=%2u lds=%6zu grid=%5u : med %.3f ms  min %.3f ms  -> %.2f TFLOP/s (%.1f%% of 157.3)\n",
+               cfgs[k].ws, cfgs[k].um ? " UM" : "   ", cfgs[k].P, cfgs[k].unroll, cfgs[k].js, cfgs[k].lds, grid_blocks(i_tiles, cfgs[k].js), med, mn,
                14.0 * pairs / (med * 1e-3) / 1e12, 14.0 * pairs / (med * 1e-3) / 1e12 / 157.3 * 100);
     }
     printf("--- placement diagnostics\n");
