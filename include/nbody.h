@@ -144,6 +144,12 @@ int nb_wait(nb_sim *s);
  * main.cpp:623-627. */
 int nb_sync(nb_sim *s, nb_body *out);
 
+/* Page-lock a host array (e.g. the storage of `std::vector<Body> bodies`) so that nb_sync
+ * DMAs straight into it instead of going through the library's staging buffer + memcpy
+ * (16.8 MB per sync at N = 262 144).  Unregister before the array is freed or reallocated. */
+int nb_host_register(void *ptr, size_t bytes);
+int nb_host_unregister(void *ptr);
+
 /* Positions only (8 bytes/body instead of 64): the fast path for a viewer that
  * only draws (main.cpp:623-627 consumer).  out holds 2*i_count floats (x,y).
  * For NB_FP64 handles values are rounded to float. */

@@ -555,11 +555,35 @@ static int ensure_staging(nb_sim *s)
     return NB_OK;
 }
 
+// Host memory made DMA-able with nb_host_register (or hipHostMalloc/hipHostRegister by the caller)
+// is written by the copy engine directly; anything else goes through the pinned staging buffer.
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int nb_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) { nb_set_error("nb_host_register: NULL argument"); return NB_EINVAL; }
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return NB_OK;
+}
+
+extern "C" int nb_host_unregister(void *ptr)
+{
+    if (!ptr) { nb_set_error("nb_host_unregister: NULL argument"); return NB_EINVAL; }
+    HIPCHK(hipHostUnregister(ptr));
+    return NB_OK;
+}
+
 extern "C" int nb_sync(nb_sim *s, nb_body *out)
 {
     if (!s || !out) { nb_set_error("nb_sync: NULL argument"); return NB_EINVAL; }
     if (bind(s)) return NB_EHIP;
-    if (ensure_staging(s)) return NB_EHIP;
+    const bool direct = is_pinned_host(out);
+    if (!direct && ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     if (s->fp64)
         pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double2 *)s->pos[s->cur], (const double *)s->mass,
@@ -568,9 +592,9 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
         pack_bodies<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float2 *)s->pos[s->cur], (const float *)s->mass,
                                                        (const float2 *)s->vel, (const float2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(direct ? (void *)out : s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    memcpy(out, s->staging, s->i_count * sizeof(nb_body));
+    if (!direct) memcpy(out, s->staging, s->i_count * sizeof(nb_body));
     return NB_OK;
 }
 

@@ -55,14 +55,16 @@ public:
         p.dt = SIMULATION_DT.load();
         sim_ = nb_create(reinterpret_cast<const nb_body *>(bodies.data()), bodies.size(), &p);
         if (!sim_) throw std::runtime_error(std::string("nb_create: ") + nb_last_error());
+        pin();
     }
-    ~Simulation() { nb_destroy(sim_); }
+    ~Simulation() { unpin(); nb_destroy(sim_); }
     Simulation(const Simulation &) = delete;
     Simulation &operator=(const Simulation &) = delete;
 
     // Simulation.hpp:67-75 — on return `bodies` is coherent (pos, vel, acc, mass, radius).
     void step()
     {
+        if (bodies.data() != pinned_) pin();   // the caller resized / replaced the vector
         const float current_dt = SIMULATION_DT.load();
         check(nb_step(sim_, current_dt, 1), "nb_step");
         check(nb_sync(sim_, reinterpret_cast<nb_body *>(bodies.data())), "nb_sync");
@@ -85,5 +87,16 @@ private:
     {
         if (rc != NB_OK) throw std::runtime_error(std::string(what) + ": " + nb_last_error());
     }
+    // page-lock the vector's storage so nb_sync DMAs straight into it
+    void pin()
+    {
+        unpin();
+        if (!bodies.empty() && nb_host_register(bodies.data(), bodies.size() * sizeof(Body)) == NB_OK) pinned_ = bodies.data();
+    }
+    void unpin()
+    {
+        if (pinned_) { nb_host_unregister(pinned_); pinned_ = nullptr; }
+    }
     nb_sim *sim_ = nullptr;
+    Body *pinned_ = nullptr;
 };

@@ -68,6 +68,7 @@ int main(int argc, char **argv)
 
     nb_sim *sim = nb_create(bodies, n, &p);
     if (!sim) DIE("nb_create: %s", nb_last_error());
+    const int pinned = nb_host_register(bodies, n * sizeof *bodies) == NB_OK;   /* nb_sync then DMAs into `bodies` */
     char desc[512];
     CHECK(nb_describe(sim, desc, sizeof desc));
     printf("%s\n", desc);
@@ -101,6 +102,7 @@ int main(int argc, char **argv)
         CHECK(nb_dump(sim, dump));
         printf("dumped to %s\n", dump);
     }
+    if (pinned) nb_host_unregister(bodies);
     nb_destroy(sim);
     free(bodies);
     return 0;
