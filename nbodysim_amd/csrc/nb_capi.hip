@@ -111,6 +111,13 @@ struct nb_sim {
     bool uniform_mass = false;      // every body has the same mass: the per-pair mass multiply is hoisted
     float um_mass = 0.f;
 
+    // symmetric path (force_sym_f32): work items and its two slab sets
+    bool sym = false;
+    uint32_t sym_items = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0;
+    SymItem *sym_items_dev = nullptr;
+    uint32_t *sym_rowbase_dev = nullptr;
+    float2 *sym_slab_s = nullptr, *sym_slab_r = nullptr;
+
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_used;
@@ -133,6 +140,8 @@ static int bind(const nb_sim *s)
 // workgroups per CU.  When i-particles are scarce (sharded or small runs) the
 // j range is cut into more slices, and P drops only when the slices would get
 // shorter than two LDS tiles.
+static bool want_sym(const nb_sim *s);
+
 // Slices are whole LDS tiles and none is empty: js = ceil(tiles / ceil(tiles / want)).
 static uint32_t even_slices(uint32_t jn, uint32_t want)
 {
@@ -183,11 +192,60 @@ static void plan(nb_sim *s)
 {
     const uint32_t n = (uint32_t)s->n, ib = (uint32_t)s->i_begin, ic = (uint32_t)s->i_count;
     s->job_all = plan_job(s, 0, n, 0);
-    s->slabs_all = s->job_all.js;
+    s->slabs_all = want_sym(s) ? 1 : s->job_all.js;      // the symmetric path leaves one summed slab
     s->job_local = plan_job(s, ib, ib + ic, 0);
     // everything but the owned block, in one launch: virtual j range [0, n - ic) with a gap at the block
     s->job_remote = plan_job(s, 0, n - ic, s->job_local.js, ib, ic);
     s->slabs_two_phase = s->job_local.js + s->job_remote.js;
+}
+
+// Symmetric path: used for whole-system (unsharded) fp32 tiled runs with eps > 0 that are big enough
+// to fill the chip with (tile, chunk-range) items.  NB_NO_SYMMETRY=1 forces the one-sided kernel.
+static bool want_sym(const nb_sim *s)
+{
+    if (getenv("NB_NO_SYMMETRY")) return false;
+    if (s->fp64 || s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
+    if (s->i_count != s->n) return false;
+    if (s->n < 8 * (size_t)SYM_SB) return false;
+    const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
+    if (tiles * s->n * sizeof(float2) > ((size_t)8 << 30)) return false;      // travelling slab cap: 8 GiB
+    return true;
+}
+
+static int plan_sym(nb_sim *s)
+{
+    const uint32_t n = (uint32_t)s->n;
+    const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
+    // chunks strictly after tile I: chunks - (I+1)*cpt (>= 0)
+    uint64_t total = 0;
+    for (uint32_t I = 0; I < tiles; ++I) { const uint32_t first = (I + 1) * cpt; if (first < chunks) total += chunks - first; }
+    const char *envl = getenv("NB_SYM_L");
+    const uint32_t target = 32u * (uint32_t)s->cus;
+    uint32_t L = envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : (uint32_t)((total + target - 1) / target);
+    if (L < 1) L = 1;
+    std::vector<SymItem> items;
+    std::vector<uint32_t> rowbase(tiles + 1, 0);
+    uint32_t row = 0;
+    for (uint32_t I = 0; I < tiles; ++I) {
+        rowbase[I] = row;
+        const uint32_t d0 = I * cpt, dcnt = chunks - d0 < cpt ? chunks - d0 : cpt;
+        items.push_back(SymItem{I, d0, dcnt, row | 0x80000000u});     // diagonal item, one-sided
+        ++row;
+        for (uint32_t c0 = (I + 1) * cpt; c0 < chunks; c0 += L) {
+            const uint32_t cnt = chunks - c0 < L ? chunks - c0 : L;
+            items.push_back(SymItem{I, c0, cnt, row});
+            ++row;
+        }
+    }
+    rowbase[tiles] = row;
+    s->sym_items = (uint32_t)items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = L;
+    HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
+    HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&s->sym_slab_s, (size_t)row * SYM_SB * sizeof(float2)));
+    HIPCHK(hipMalloc((void **)&s->sym_slab_r, (size_t)tiles * n * sizeof(float2)));
+    HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return NB_OK;
 }
 
 static void free_all(nb_sim *s)
@@ -201,6 +259,8 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->mass); (void)hipFree(s->radius);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
     (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
+    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev);
+    (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
     if (s->staging) (void)hipHostFree(s->staging);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -301,6 +361,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->ered_blocks = (s->i_count + BLOCK - 1) / BLOCK;
     if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
 
+    s->sym = want_sym(s);
+    if (s->sym && plan_sym(s) != NB_OK) { free_all(s); return nullptr; }
     if (do_upload(s, init) != NB_OK) { free_all(s); return nullptr; }
     return s;
 }
@@ -386,9 +448,34 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
         (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, j.gap_begin, j.gap_len);
 }
 
+// Whole-system force through the symmetric kernel; leaves the summed acceleration in slab 0.
+static int launch_force_sym(nb_sim *s)
+{
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+    const float eps2 = s->p.eps * s->p.eps;
+    const float2 *pos = (const float2 *)s->pos[s->cur];
+    const float *mass = (const float *)s->mass;
+    const uint32_t n = (uint32_t)s->n;
+    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
+    if (s->uniform_mass) {
+        if (quake) force_sym_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, s->um_mass);
+        else       force_sym_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, s->um_mass);
+    } else {
+        if (quake) force_sym_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, 1.0f);
+        else       force_sym_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, 1.0f);
+    }
+    HIPCHK(hipGetLastError());
+    if (s->prof && prof_end(s, pr)) return NB_EHIP;
+    sym_gather<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, n, (float2 *)s->partial);
+    HIPCHK(hipGetLastError());
+    return NB_OK;
+}
+
 static int launch_force(nb_sim *s, const ForceJob &j)
 {
     if (j.j_end <= j.j_begin || j.js == 0) return NB_OK;
+    if (s->sym && &j == &s->job_all) return launch_force_sym(s);
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
     const bool guard = s->p.eps == 0.0f;
@@ -688,11 +775,12 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
-             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, s->cus);
+             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
+             (int)s->sym, s->sym_items, s->sym_L, s->cus);
     return NB_OK;
 }

@@ -262,6 +262,193 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 }
 
 // ---------------------------------------------------------------------------
+// force_sym_f32 — symmetric (Newton's third law) fast path: every UNORDERED pair
+// is evaluated once and applied to both particles.
+//
+// A wave keeps 2P "stationary" particles per lane (512 per wave at P = 4, 2048 per
+// workgroup) in registers and streams 64-particle "travelling" chunks through its
+// lanes: one particle per lane together with its accumulator, rotated by one lane
+// per step with ds_bpermute_b32 (the LDS crossbar: no VALU cost, no LDS storage),
+// so after 64 steps every stationary lane has met every travelling particle and the
+// travelling accumulators are back in their home lanes.  A body (two stationary
+// particles x one travelling particle, BOTH directions = 4 ordered interactions)
+// costs 10 packed ops + 2 v_rsq_f32 (12 + 2 with individual masses) against
+// 2 x (8|9 + 2) for the one-sided kernel: ~1.6x fewer VALU cycles per interaction.
+//
+// Work items (built on the host, one workgroup each):
+//   diagonal item  (I)         block-tile I against the chunks of its OWN 2048 particles,
+//                              one-sided (each ordered pair is met from both ends anyway);
+//   symmetric item (I, c0, cnt) block-tile I against cnt chunks that lie strictly AFTER
+//                              tile I: stationary side accumulates in registers across the
+//                              chunks, travelling side is combined over the 4 waves through
+//                              LDS (wave order) and written once per chunk.
+// Outputs (all plain stores, summed later in a fixed order -> deterministic):
+//   slab_S[row][2048]   stationary partial of the item (row = item.s_row)
+//   slab_R[I][n]        travelling partials: the force of tile I on particles after it
+// sym_gather adds, for particle k of tile g: its slab_S rows + slab_R[0..g-1][k].
+// Requires eps > 0 (r = 0 then contributes exactly 0); eps == 0 uses force_tiled_f32<GUARD>.
+// ---------------------------------------------------------------------------
+struct SymItem { uint32_t tile, c0, cnt, s_row_diag; };   // s_row_diag = row | (diag << 31)
+
+constexpr int SYM_P = 4;                                 // packed stationary pairs per lane
+constexpr uint32_t SYM_WT = 64 * 2 * SYM_P;              // stationary particles per wave  (512)
+constexpr uint32_t SYM_SB = 4 * SYM_WT;                  // ... per workgroup / block-tile (2048)
+constexpr uint32_t SYM_CH = 64;                          // travelling chunk
+
+__device__ __forceinline__ float lane_rot(float v, int addr)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+template <int RSQ, bool UM, bool DIAG>
+__device__ __forceinline__
+void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&mi)[SYM_P],
+                v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], float eps2, float um_mass, float2 (*red)[4][64])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);    // pull from lane+1: particles move down one lane per step
+    const v2f e2 = {eps2, eps2};
+
+    // chunk c0 into registers
+    float xq = PAD_XY, yq = PAD_XY, mq = 0.f;
+    {
+        const uint32_t j = c0 * SYM_CH + lane;
+        if (j < n) { const float2 pj = pos[j]; xq = pj.x; yq = pj.y; if constexpr (!UM) mq = mass[j]; }
+    }
+    for (uint32_t c = 0; c < cnt; ++c) {
+        // next chunk in flight behind the 64 steps
+        float xn = PAD_XY, yn = PAD_XY, mn = 0.f;
+        {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (c + 1 < cnt && j < n) { const float2 pj = pos[j]; xn = pj.x; yn = pj.y; if constexpr (!UM) mn = mass[j]; }
+        }
+        v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};
+#pragma unroll 2
+        for (int step = 0; step < 64; ++step) {
+            // positions of the next step do not depend on this step's arithmetic: rotate them early
+            const float xr = lane_rot(xq, addr), yr = lane_rot(yq, addr);
+            float mr = 0.f;
+            if constexpr (!UM) mr = lane_rot(mq, addr);
+            const v2f xj = {xq, xq}, yj = {yq, yq};
+#pragma unroll
+            for (int p = 0; p < SYM_P; ++p) {
+                const v2f dx = xj - xi[p];
+                const v2f dy = yj - yi[p];
+                v2f r2 = __builtin_elementwise_fma(dx, dx, e2);
+                r2 = __builtin_elementwise_fma(dy, dy, r2);
+                v2f inv;
+                if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                else inv = quake_rsqrt2(r2);
+                const v2f inv3 = inv * (inv * inv);
+                if constexpr (UM) {
+                    ax[p] = __builtin_elementwise_fma(inv3, dx, ax[p]);
+                    ay[p] = __builtin_elementwise_fma(inv3, dy, ay[p]);
+                    if constexpr (!DIAG) {
+                        aqx = __builtin_elementwise_fma(-inv3, dx, aqx);
+                        aqy = __builtin_elementwise_fma(-inv3, dy, aqy);
+                    }
+                } else {
+                    const v2f si = (v2f){mq, mq} * inv3;       // force ON the stationary pair: m_j / r^3
+                    ax[p] = __builtin_elementwise_fma(si, dx, ax[p]);
+                    ay[p] = __builtin_elementwise_fma(si, dy, ay[p]);
+                    if constexpr (!DIAG) {
+                        const v2f sj = mi[p] * inv3;           // force ON the travelling particle: m_i / r^3
+                        aqx = __builtin_elementwise_fma(-sj, dx, aqx);
+                        aqy = __builtin_elementwise_fma(-sj, dy, aqy);
+                    }
+                }
+            }
+            xq = xr; yq = yr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) {
+                aqx.x = lane_rot(aqx.x, addr); aqx.y = lane_rot(aqx.y, addr);
+                aqy.x = lane_rot(aqy.x, addr); aqy.y = lane_rot(aqy.y, addr);
+            }
+        }
+        if constexpr (!DIAG) {
+            // after 64 rotations lane l holds the accumulator of travelling particle (chunk, l):
+            // combine the 4 waves (4 different stationary sets) in wave order and store once.
+            float2 r = make_float2(aqx.x + aqx.y, aqy.x + aqy.y);
+            if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; }
+            float2 (*rb)[64] = red[c & 1u];
+            rb[w][lane] = r;
+            __syncthreads();
+            if (w == 0) {
+                const uint32_t j = (c0 + c) * SYM_CH + lane;
+                float2 a = rb[0][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn;
+        if constexpr (!UM) mq = mn;
+    }
+}
+
+template <int RSQ, bool UM>
+__global__ __launch_bounds__(BLOCK)
+void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                   const SymItem *__restrict__ items,
+                   float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
+                   uint32_t n, float eps2, float um_mass)
+{
+    __shared__ float2 red[2][4][64];
+    const SymItem it = items[blockIdx.x];
+    const bool diag = (it.s_row_diag >> 31) != 0;
+    const uint32_t s_row = it.s_row_diag & 0x7fffffffu;
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+
+    v2f xi[SYM_P], yi[SYM_P], mi[SYM_P], ax[SYM_P], ay[SYM_P];
+    uint32_t li[SYM_P];
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        li[p] = w * SYM_WT + (uint32_t)p * 128u + 2u * lane;      // index inside the block-tile
+        const uint32_t g0 = it.tile * SYM_SB + li[p], g1 = g0 + 1;
+        // particles past the end sit at PAD_XY with mass 0: they neither feel nor exert force
+        float2 p0 = make_float2(PAD_XY, PAD_XY), p1 = p0;
+        float m0 = 0.f, m1 = 0.f;
+        if (g0 < n) { p0 = pos[g0]; if constexpr (!UM) m0 = mass[g0]; }
+        if (g1 < n) { p1 = pos[g1]; if constexpr (!UM) m1 = mass[g1]; }
+        xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; mi[p] = (v2f){m0, m1};
+        ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
+    }
+    float2 *__restrict__ rrow = slab_r + (size_t)it.tile * n;
+    if (diag) sym_chunks<RSQ, UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    else      sym_chunks<RSQ, UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+
+    float2 *__restrict__ out = slab_s + (size_t)s_row * SYM_SB;
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
+        *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+    }
+}
+
+// acc_sum[k] = sum of particle k's stationary rows (its tile's items, in item order)
+//            + sum over earlier tiles I of slab_r[I][k]  (in tile order).
+__global__ __launch_bounds__(BLOCK)
+void sym_gather(const float2 *__restrict__ slab_s, const float2 *__restrict__ slab_r,
+                const uint32_t *__restrict__ rowbase, uint32_t n, float2 *__restrict__ acc_sum)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
+    float2 a = make_float2(0.f, 0.f);
+    for (uint32_t r = rowbase[g]; r < rowbase[g + 1]; ++r) {
+        const float2 b = slab_s[(size_t)r * SYM_SB + loc];
+        a.x += b.x; a.y += b.y;
+    }
+    for (uint32_t i = 0; i < g; ++i) {
+        const float2 b = slab_r[(size_t)i * n + k];
+        a.x += b.x; a.y += b.y;
+    }
+    acc_sum[k] = a;
+}
+
+// ---------------------------------------------------------------------------
 // force_seq_f32 — reference summation order (NB_SUM_SEQUENTIAL).
 // One lane per i, j ascending over the WHOLE range in one running sum, every
 // operation individually rounded (no FMA), guard `r_sq > 0` kept: the exact

@@ -204,6 +204,37 @@ def test_uniform_mass_fast_path_matches_general_path(nbo):
         assert "uniform_mass=0" in sim.describe()
 
 
+@pytest.mark.parametrize("n", [16384, 20000, 70001])
+@pytest.mark.parametrize("masses", ["uniform", "individual"])
+@pytest.mark.parametrize("rsqrt", ["exact", "quake"])
+def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt):
+    """force_sym_f32 evaluates each unordered pair once (Newton's third law); it must agree with
+    the one-sided kernel and with the fp64 direct sum on the global force scale, and conserve
+    momentum better than the one-sided sum (its pair forces are exactly opposite)."""
+    ic = nb.plummer_2d(n, 5)
+    if masses == "individual":
+        rng = np.random.default_rng(n)
+        ic["mass"] = (rng.uniform(0.5, 1.5, n) / n).astype(np.float32)
+    res = {}
+    for tag, env in (("sym", None), ("one_sided", "1")):
+        if env:
+            os.environ["NB_NO_SYMMETRY"] = env
+        try:
+            with nb.Simulation(ic, eps=0.02, rsqrt=rsqrt) as sim:
+                assert f"symmetric={0 if env else 1}" in sim.describe()
+                res[tag] = sim.accelerations().astype(np.float64)
+        finally:
+            os.environ.pop("NB_NO_SYMMETRY", None)
+    scale = np.max(np.abs(res["one_sided"]))
+    assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
+    if rsqrt == "exact":
+        ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), f32(0.02))
+        assert np.max(np.abs(res["sym"] - np.stack([ax, ay], 1))) < 2e-5 * scale
+    m = ic["mass"].astype(np.float64)[:, None]
+    drift_sym = np.abs((m * res["sym"]).sum(0)).max()
+    assert drift_sym < 1e-6 * np.abs(m * res["sym"]).sum(0).max()
+
+
 # ------------------------------------------------------------------- fp64 ---
 def test_fp64_matches_fp64_direct(gold, nbo):
     flat = gold["ic_plummer_1024"]
