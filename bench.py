@@ -197,10 +197,12 @@ def main() -> None:
                 "frac": achieved / (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2),
                 "traffic": traffic,
                 "flop_per_pair": FLOP_PER_PAIR,
-                "kernel": "force_tiled_f32" if args.precision == "fp32" else "force_tiled_f64",
+                "kernel": ("force_sym_f32" if "symmetric=1" in inner.describe() else "force_tiled_f32") if args.precision == "fp32" else "force_tiled_f64",
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
                 "note": "fp32 vector-ALU bound (no dense contraction for MFMA; the f32 MFMA peak equals the vector peak, 157.3 TF); "
+                        "achieved = 14 ALGORITHMIC flop x N^2 ordered pairs / kernel time; force_sym_f32 evaluates each unordered pair "
+                        "once (Newton's third law), so it executes fewer flops than it delivers; "
                         "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B",
                 "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
             },

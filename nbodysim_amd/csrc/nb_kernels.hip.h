@@ -290,7 +290,16 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 // ---------------------------------------------------------------------------
 struct SymItem { uint32_t tile, c0, cnt, s_row_diag; };   // s_row_diag = row | (diag << 31)
 
-constexpr int SYM_P = 4;                                 // packed stationary pairs per lane
+#ifndef NB_SYM_UNROLL
+#define NB_SYM_UNROLL 2      // rotation steps unrolled together (tools/sym_sweep.sh)
+#endif
+#ifndef NB_SYM_WAVES
+#define NB_SYM_WAVES 1       // __launch_bounds__ minimum waves per SIMD for force_sym_f32
+#endif
+#ifndef NB_SYM_P
+#define NB_SYM_P 4
+#endif
+constexpr int SYM_P = NB_SYM_P;                          // packed stationary pairs per lane
 constexpr uint32_t SYM_WT = 64 * 2 * SYM_P;              // stationary particles per wave  (512)
 constexpr uint32_t SYM_SB = 4 * SYM_WT;                  // ... per workgroup / block-tile (2048)
 constexpr uint32_t SYM_CH = 64;                          // travelling chunk
@@ -325,7 +334,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
             if (c + 1 < cnt && j < n) { const float2 pj = pos[j]; xn = pj.x; yn = pj.y; if constexpr (!UM) mn = mass[j]; }
         }
         v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};
-#pragma unroll 2
+#pragma unroll NB_SYM_UNROLL
         for (int step = 0; step < 64; ++step) {
             // positions of the next step do not depend on this step's arithmetic: rotate them early
             const float xr = lane_rot(xq, addr), yr = lane_rot(yq, addr);
@@ -389,7 +398,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
 }
 
 template <int RSQ, bool UM>
-__global__ __launch_bounds__(BLOCK)
+__global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
 void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
                    const SymItem *__restrict__ items,
                    float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,

@@ -20,6 +20,8 @@ template <int MODE> __device__ __forceinline__ float rot(float v, int addr)
 template <int P, int Q, int MODE>
 __global__ __launch_bounds__(256) void probe(const float2 *pos, float2 *out, int n, int chunks, float eps2)
 {
+    __shared__ float2 lpos[4][Q][64];
+    __shared__ float2 lacc[4][Q][64];
     const int lane = threadIdx.x & 63;
     const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int addr = ((lane + 1) & 63) * 4;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void probe(const float2 *pos, float2 *out, int
         for (int q = 0; q < Q; ++q) {
             int j = ((c * Q + q) * 64 + lane + gw * 7) % n;
             xq[q] = pos[j].x; yq[q] = pos[j].y; aqx[q] = (v2f){0, 0}; aqy[q] = (v2f){0, 0};
+            if constexpr (MODE == 6) { lpos[threadIdx.x >> 6][q][lane] = pos[j]; lacc[threadIdx.x >> 6][q][lane] = make_float2(0, 0); }
         }
 #pragma unroll 2
         for (int step = 0; step < 64; ++step) {
@@ -57,7 +60,25 @@ __global__ __launch_bounds__(256) void probe(const float2 *pos, float2 *out, int
                     }
                 }
             }
-            if constexpr (MODE == 0 || MODE == 1) {
+            if constexpr (MODE == 4) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { xq[q] = rot<0>(xq[q], addr); yq[q] = rot<0>(yq[q], addr);
+                    asm volatile("" : "+v"(aqx[q]), "+v"(aqy[q])); }
+            } else if constexpr (MODE == 5) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(xq[q]), "+v"(yq[q]), "+v"(aqx[q]), "+v"(aqy[q]));
+            } else if constexpr (MODE == 6) {
+                // positions come from LDS with a rotating index; the step's j-side sum goes back with ds_add_f32
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int slot = (lane + step + 1) & 63, cur = (lane + step) & 63;
+                    atomicAdd(&lacc[threadIdx.x >> 6][q][cur].x, aqx[q].x + aqx[q].y);
+                    atomicAdd(&lacc[threadIdx.x >> 6][q][cur].y, aqy[q].x + aqy[q].y);
+                    aqx[q] = (v2f){0, 0}; aqy[q] = (v2f){0, 0};
+                    const float2 pn = lpos[threadIdx.x >> 6][q][slot];
+                    xq[q] = pn.x; yq[q] = pn.y;
+                }
+            } else if constexpr (MODE == 0 || MODE == 1) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     xq[q] = rot<MODE>(xq[q], addr); yq[q] = rot<MODE>(yq[q], addr);
@@ -69,7 +90,8 @@ __global__ __launch_bounds__(256) void probe(const float2 *pos, float2 *out, int
                 for (int q = 0; q < Q; ++q) { xq[q] = rot<0>(xq[q], addr); yq[q] = rot<0>(yq[q], addr); }
             }
         }
-        for (int q = 0; q < Q; ++q) { sx += aqx[q].x + aqx[q].y; sy += aqy[q].x + aqy[q].y; }
+        for (int q = 0; q < Q; ++q) { sx += aqx[q].x + aqx[q].y; sy += aqy[q].x + aqy[q].y;
+            if constexpr (MODE == 6) { sx += lacc[threadIdx.x >> 6][q][lane].x; sy += lacc[threadIdx.x >> 6][q][lane].y; } }
     }
     float2 r = make_float2(sx, sy);
     for (int p = 0; p < P; ++p) { r.x += ax[p].x + ax[p].y; r.y += ay[p].x + ay[p].y; }
@@ -105,13 +127,11 @@ int main()
     float2 *pos, *out; CK(hipMalloc(&pos, n * 8)); CK(hipMalloc(&out, 256 * 8 * 256 * 8));
     CK(hipMemcpy(pos, h.data(), n * 8, hipMemcpyHostToDevice));
     run<4, 1, 3>(pos, out, n, "one-sided (today), bpermute x,y");
-    run<4, 1, 2>(pos, out, n, "two-sided, no rotation (bound)");
-    run<4, 1, 0>(pos, out, n, "two-sided, ds_bpermute");
+    run<4, 1, 5>(pos, out, n, "two-sided, NO rotation (bound)");
+    run<4, 1, 4>(pos, out, n, "two-sided, rotate x,y only (2 bperm)");
+    run<4, 1, 0>(pos, out, n, "two-sided, 6 bpermute");
+    run<4, 1, 6>(pos, out, n, "two-sided, LDS read + 2 ds_add_f32");
+    run<4, 2, 6>(pos, out, n, "two-sided, LDS read + 2 ds_add_f32");
     run<4, 1, 1>(pos, out, n, "two-sided, DPP wave_ror");
-    run<4, 2, 0>(pos, out, n, "two-sided, ds_bpermute");
-    run<4, 2, 1>(pos, out, n, "two-sided, DPP wave_ror");
-    run<2, 2, 0>(pos, out, n, "two-sided, ds_bpermute");
-    run<2, 4, 0>(pos, out, n, "two-sided, ds_bpermute");
-    run<2, 1, 0>(pos, out, n, "two-sided, ds_bpermute");
     return 0;
 }
