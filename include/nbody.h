@@ -110,6 +110,13 @@ typedef struct nb_params {
                               position replicas (n * 2 * sizeof(real) bytes each, (x,y)
                               interleaved) so that a host-side collective can fill them;
                               NULL = allocated by the library */
+    int32_t  shard_rank;   /* this handle's rank and the number of ranks of a sharded run     */
+    int32_t  shard_world;  /* (0/0 or x/1 = not sharded by the library's symmetric protocol)  */
+    void    *acc_buffers[2];/* optional caller-owned device buffers of the symmetric sharded
+                              protocol: [0] n*(ax,ay) floats = this rank's PARTIAL acceleration
+                              of every particle (reduce-scatter input), [1] i_count*(ax,ay) =
+                              the summed acceleration of the owned block (its output);
+                              NULL = allocated by the library */
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
@@ -204,6 +211,18 @@ int nb_read_bodies(const char *path, nb_body *out, size_t n);
  * Stream ordering between the two calls and the collective is the caller's
  * (they share params.stream, or use events). */
 enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
+/* Which exchange a sharded handle needs between nb_step_begin and nb_step_finish:
+ *   NB_SHARD_ALLGATHER   (i_count < n): begin = local-tile force; host all-gathers the positions
+ *                        into nb_pos_buffer(CURRENT) (may overlap begin); finish = remote force,
+ *                        kick, drift.  One-sided kernels; one collective per step.
+ *   NB_SHARD_SYMMETRIC   (shard_world > 1, fp32 tiled, eps > 0, large n): every rank evaluates a
+ *                        balanced share of the UNORDERED pairs with the symmetric kernel:
+ *                        begin = partial acceleration of ALL particles into nb_acc_buffer(0);
+ *                        host reduce-scatters it (sum) into nb_acc_buffer(1); finish = kick, drift
+ *                        of the owned block; host all-gathers positions before the next begin. */
+enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2 };
+int   nb_shard_protocol(const nb_sim *s);
+void *nb_acc_buffer(nb_sim *s, int which);   /* 0: full-n partial, 1: owned block sum (NULL if unused) */
 int   nb_step_begin(nb_sim *s, float dt);
 int   nb_step_finish(nb_sim *s);
 void *nb_pos_buffer(nb_sim *s, int which);   /* device pointer, n*(x,y) reals */

@@ -27,6 +27,7 @@ NB_SUM_TILED, NB_SUM_SEQUENTIAL = 0, 1
 NB_EXTRA_VCLAMP, NB_EXTRA_BOUNDARY = 1, 2
 NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
+NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC = 0, 1, 2
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(
@@ -63,6 +64,9 @@ class nb_params(C.Structure):
         ("i_count", C.c_uint64),
         ("stream", C.c_void_p),
         ("pos_buffers", C.c_void_p * 2),
+        ("shard_rank", C.c_int32),
+        ("shard_world", C.c_int32),
+        ("acc_buffers", C.c_void_p * 2),
     ]
 
 
@@ -92,6 +96,8 @@ PROTOTYPES = {
     "nb_step_finish": (C.c_int, [C.c_void_p]),
     "nb_pos_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_stream": (C.c_void_p, [C.c_void_p]),
+    "nb_shard_protocol": (C.c_int, [C.c_void_p]),
+    "nb_acc_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

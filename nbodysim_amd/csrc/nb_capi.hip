@@ -115,8 +115,12 @@ struct nb_sim {
     bool sym = false;
     uint32_t sym_items = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0;
     SymItem *sym_items_dev = nullptr;
-    uint32_t *sym_rowbase_dev = nullptr;
+    uint32_t *sym_rowbase_dev = nullptr, *sym_tile_row_dev = nullptr;
     float2 *sym_slab_s = nullptr, *sym_slab_r = nullptr;
+    // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
+    bool sym_sharded = false;
+    float2 *acc_full = nullptr, *acc_owned = nullptr;   // reduce-scatter input (n) / output (i_count)
+    bool own_acc = true;
 
     // profiling
     bool prof = false;
@@ -199,52 +203,89 @@ static void plan(nb_sim *s)
     s->slabs_two_phase = s->job_local.js + s->job_remote.js;
 }
 
-// Symmetric path: used for whole-system (unsharded) fp32 tiled runs with eps > 0 that are big enough
-// to fill the chip with (tile, chunk-range) items.  NB_NO_SYMMETRY=1 forces the one-sided kernel.
-static bool want_sym(const nb_sim *s)
+// Symmetric path: fp32 tiled runs with eps > 0 that are big enough to fill the chip with
+// (tile, chunk-range) items — either the whole system on one GPU, or (shard_world > 1) this rank's
+// share of the tiles of a sharded run.  NB_NO_SYMMETRY=1 forces the one-sided kernels.
+static bool sym_eligible(const nb_sim *s)
 {
     if (getenv("NB_NO_SYMMETRY")) return false;
     if (s->fp64 || s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
-    if (s->i_count != s->n) return false;
+    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
     if (s->n < 8 * (size_t)SYM_SB) return false;
     const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
-    if (tiles * s->n * sizeof(float2) > ((size_t)8 << 30)) return false;      // travelling slab cap: 8 GiB
+    const size_t world = s->p.shard_world > 1 ? (size_t)s->p.shard_world : 1;
+    if ((tiles + world - 1) / world * s->n * sizeof(float2) > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
     return true;
+}
+
+static bool want_sym(const nb_sim *s)          // single handle owns everything
+{
+    return s->i_count == s->n && s->p.shard_world <= 1 && sym_eligible(s);
+}
+
+static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
+{
+    return s->p.shard_world > 1 && s->i_count != s->n && sym_eligible(s) &&
+           s->n / (size_t)s->p.shard_world >= 2 * (size_t)SYM_SB;
+}
+
+// Tiles are dealt to ranks in snake order (0..W-1, W-1..0, ...): tile I costs ~(T - I) units, so
+// consecutive rounds in opposite directions give every rank the same total to within one tile.
+static uint32_t tile_owner(uint32_t I, uint32_t world)
+{
+    const uint32_t round = I / world, k = I % world;
+    return (round & 1u) ? world - 1 - k : k;
 }
 
 static int plan_sym(nb_sim *s)
 {
     const uint32_t n = (uint32_t)s->n;
+    const uint32_t world = s->sym_sharded ? (uint32_t)s->p.shard_world : 1u;
+    const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
-    // chunks strictly after tile I: chunks - (I+1)*cpt (>= 0)
+    // chunks strictly after tile I: chunks - (I+1)*cpt (>= 0); only this rank's tiles count
     uint64_t total = 0;
-    for (uint32_t I = 0; I < tiles; ++I) { const uint32_t first = (I + 1) * cpt; if (first < chunks) total += chunks - first; }
+    for (uint32_t I = 0; I < tiles; ++I) {
+        if (tile_owner(I, world) != rank) continue;
+        const uint32_t first = (I + 1) * cpt;
+        if (first < chunks) total += chunks - first;
+    }
     const char *envl = getenv("NB_SYM_L");
     const uint32_t target = 32u * (uint32_t)s->cus;
     uint32_t L = envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : (uint32_t)((total + target - 1) / target);
     if (L < 1) L = 1;
     std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase(tiles + 1, 0);
-    uint32_t row = 0;
+    std::vector<uint32_t> rowbase(tiles + 1, 0), tile_row(tiles, SYM_NONE);
+    uint32_t row = 0, rrow = 0;
     for (uint32_t I = 0; I < tiles; ++I) {
         rowbase[I] = row;
+        if (tile_owner(I, world) != rank) continue;
+        tile_row[I] = rrow;
         const uint32_t d0 = I * cpt, dcnt = chunks - d0 < cpt ? chunks - d0 : cpt;
-        items.push_back(SymItem{I, d0, dcnt, row | 0x80000000u});     // diagonal item, one-sided
-        ++row;
+        items.push_back(SymItem{I, d0, dcnt, row++, rrow, 1u, 0u, 0u});       // diagonal item, one-sided
         for (uint32_t c0 = (I + 1) * cpt; c0 < chunks; c0 += L) {
             const uint32_t cnt = chunks - c0 < L ? chunks - c0 : L;
-            items.push_back(SymItem{I, c0, cnt, row});
-            ++row;
+            items.push_back(SymItem{I, c0, cnt, row++, rrow, 0u, 0u, 0u});
         }
+        ++rrow;
     }
     rowbase[tiles] = row;
     s->sym_items = (uint32_t)items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = L;
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&s->sym_slab_s, (size_t)row * SYM_SB * sizeof(float2)));
-    HIPCHK(hipMalloc((void **)&s->sym_slab_r, (size_t)tiles * n * sizeof(float2)));
+    HIPCHK(hipMalloc((void **)&s->sym_tile_row_dev, tile_row.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * sizeof(float2)));
+    HIPCHK(hipMalloc((void **)&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * sizeof(float2)));
     HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_tile_row_dev, tile_row.data(), tile_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (s->sym_sharded) {
+        if (s->p.acc_buffers[0]) { s->acc_full = (float2 *)s->p.acc_buffers[0]; s->acc_owned = (float2 *)s->p.acc_buffers[1]; s->own_acc = false; }
+        else {
+            HIPCHK(hipMalloc((void **)&s->acc_full, (size_t)n * sizeof(float2)));
+            HIPCHK(hipMalloc((void **)&s->acc_owned, s->i_count * sizeof(float2)));
+        }
+    }
     return NB_OK;
 }
 
@@ -259,7 +300,8 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->mass); (void)hipFree(s->radius);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
     (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
-    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev);
+    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_tile_row_dev);
+    if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
     if (s->staging) (void)hipHostFree(s->staging);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -318,6 +360,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (p.i_count == 0) { p.i_begin = 0; p.i_count = n; }
     if (p.i_begin + p.i_count > n) { nb_set_error("nb_create: owned block [%llu,+%llu) exceeds n=%zu", (unsigned long long)p.i_begin, (unsigned long long)p.i_count, n); return nullptr; }
     if ((p.pos_buffers[0] == nullptr) != (p.pos_buffers[1] == nullptr)) { nb_set_error("nb_create: give both pos_buffers or none"); return nullptr; }
+    if ((p.acc_buffers[0] == nullptr) != (p.acc_buffers[1] == nullptr)) { nb_set_error("nb_create: give both acc_buffers or none"); return nullptr; }
+    if (p.shard_world < 0 || (p.shard_world > 1 && (p.shard_rank < 0 || p.shard_rank >= p.shard_world))) { nb_set_error("nb_create: bad shard_rank/shard_world %d/%d", p.shard_rank, p.shard_world); return nullptr; }
 
     int ndev = nb_device_count();
     if (ndev <= 0) { nb_set_error("nb_create: no HIP device visible (this library has no CPU path)"); return nullptr; }
@@ -362,7 +406,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
 
     s->sym = want_sym(s);
-    if (s->sym && plan_sym(s) != NB_OK) { free_all(s); return nullptr; }
+    s->sym_sharded = want_sym_sharded(s);
+    if ((s->sym || s->sym_sharded) && plan_sym(s) != NB_OK) { free_all(s); return nullptr; }
     if (do_upload(s, init) != NB_OK) { free_all(s); return nullptr; }
     return s;
 }
@@ -448,7 +493,9 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
         (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, j.gap_begin, j.gap_len);
 }
 
-// Whole-system force through the symmetric kernel; leaves the summed acceleration in slab 0.
+// Force through the symmetric kernel over the items held by this handle.  Unsharded: leaves the
+// summed acceleration in slab 0.  Sharded: leaves this rank's partial acceleration of ALL particles
+// in acc_full (the host reduce-scatters it into acc_owned).
 static int launch_force_sym(nb_sim *s)
 {
     std::pair<hipEvent_t, hipEvent_t> pr;
@@ -467,7 +514,8 @@ static int launch_force_sym(nb_sim *s)
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    sym_gather<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, n, (float2 *)s->partial);
+    sym_gather<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, s->sym_tile_row_dev, n,
+                                                                 s->sym_sharded ? s->acc_full : (float2 *)s->partial);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
@@ -538,7 +586,7 @@ static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double d
 // stepping
 // ---------------------------------------------------------------------------
 static bool sharded(const nb_sim *s) { return s->i_count != s->n; }
-static bool two_phase(const nb_sim *s) { return sharded(s) && s->p.sum_order != NB_SUM_SEQUENTIAL; }
+static bool two_phase(const nb_sim *s) { return sharded(s) && s->p.sum_order != NB_SUM_SEQUENTIAL && !s->sym_sharded; }
 
 extern "C" int nb_step_begin(nb_sim *s, float dt)
 {
@@ -548,6 +596,7 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     s->in_step = true;
+    if (s->sym_sharded) return launch_force_sym(s);   // partial acceleration of every particle
     // local j-block first: its positions are already resident, so this overlaps the exchange
     if (two_phase(s)) return launch_force(s, s->job_local);
     return NB_OK;
@@ -561,6 +610,19 @@ extern "C" int nb_step_finish(nb_sim *s)
     s->in_step = false;
     int rc;
     uint32_t nslabs;
+    if (s->sym_sharded) {
+        // the host has reduce-scattered acc_full into acc_owned: it is the one slab of the owned block
+        const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+        const int nxt = s->cur ^ 1;
+        const float dt = s->pending_dt;
+        integrate<float, false><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
+                                                            (float2 *)s->acc, s->acc_owned, 1u, (uint32_t)s->i_begin, ic, dt, dt,
+                                                            s->p.extras, INTEG_KICK | INTEG_DRIFT);
+        HIPCHK(hipGetLastError());
+        s->cur ^= 1;
+        s->frame += 1;
+        return NB_OK;
+    }
     if (two_phase(s)) {
         if ((rc = launch_force(s, s->job_remote))) return rc;
         nslabs = s->slabs_two_phase;
@@ -735,6 +797,16 @@ extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
 extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
 extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" int nb_shard_protocol(const nb_sim *s)
+{
+    if (!s || s->i_count == s->n) return NB_SHARD_NONE;
+    return s->sym_sharded ? NB_SHARD_SYMMETRIC : NB_SHARD_ALLGATHER;
+}
+extern "C" void *nb_acc_buffer(nb_sim *s, int which)
+{
+    if (!s || !s->sym_sharded) return nullptr;
+    return which == 0 ? (void *)s->acc_full : (void *)s->acc_owned;
+}
 
 extern "C" int nb_dump(nb_sim *s, const char *path)
 {
@@ -781,6 +853,6 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
-             (int)s->sym, s->sym_items, s->sym_L, s->cus);
+             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->cus);
     return NB_OK;
 }

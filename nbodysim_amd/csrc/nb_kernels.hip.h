@@ -284,11 +284,15 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 //                              LDS (wave order) and written once per chunk.
 // Outputs (all plain stores, summed later in a fixed order -> deterministic):
 //   slab_S[row][2048]   stationary partial of the item (row = item.s_row)
-//   slab_R[I][n]        travelling partials: the force of tile I on particles after it
-// sym_gather adds, for particle k of tile g: its slab_S rows + slab_R[0..g-1][k].
+//   slab_R[r][n]        travelling partials: the force of tile I (row r = item.r_row) on
+//                       particles after it
+// sym_gather adds, for particle k of tile g: its slab_S rows + slab_R[row(I)][k] for I < g.
+// A rank of a sharded run holds the items of the tiles it was dealt (tile_row[I] != NONE);
+// its gather then yields a PARTIAL acceleration for every particle, and the ranks' partials
+// are summed by the host's reduce-scatter.
 // Requires eps > 0 (r = 0 then contributes exactly 0); eps == 0 uses force_tiled_f32<GUARD>.
 // ---------------------------------------------------------------------------
-struct SymItem { uint32_t tile, c0, cnt, s_row_diag; };   // s_row_diag = row | (diag << 31)
+struct SymItem { uint32_t tile, c0, cnt, s_row, r_row, diag, pad0, pad1; };   // 32 bytes
 
 #ifndef NB_SYM_UNROLL
 #define NB_SYM_UNROLL 2      // rotation steps unrolled together (tools/sym_sweep.sh)
@@ -406,8 +410,8 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 {
     __shared__ float2 red[2][4][64];
     const SymItem it = items[blockIdx.x];
-    const bool diag = (it.s_row_diag >> 31) != 0;
-    const uint32_t s_row = it.s_row_diag & 0x7fffffffu;
+    const bool diag = it.diag != 0;
+    const uint32_t s_row = it.s_row;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
 
     v2f xi[SYM_P], yi[SYM_P], mi[SYM_P], ax[SYM_P], ay[SYM_P];
@@ -424,7 +428,7 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
         xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; mi[p] = (v2f){m0, m1};
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
-    float2 *__restrict__ rrow = slab_r + (size_t)it.tile * n;
+    float2 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
     if (diag) sym_chunks<RSQ, UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     else      sym_chunks<RSQ, UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
 
@@ -436,11 +440,15 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
     }
 }
 
-// acc_sum[k] = sum of particle k's stationary rows (its tile's items, in item order)
-//            + sum over earlier tiles I of slab_r[I][k]  (in tile order).
+// acc_sum[k] = sum of particle k's stationary rows (its tile's items, in item order; none if the
+//              tile belongs to another rank: rowbase[g] == rowbase[g+1])
+//            + sum over earlier tiles I held here of slab_r[tile_row[I]][k]  (in tile order).
+constexpr uint32_t SYM_NONE = 0xffffffffu;
+
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const float2 *__restrict__ slab_s, const float2 *__restrict__ slab_r,
-                const uint32_t *__restrict__ rowbase, uint32_t n, float2 *__restrict__ acc_sum)
+                const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row,
+                uint32_t n, float2 *__restrict__ acc_sum)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
@@ -451,7 +459,9 @@ void sym_gather(const float2 *__restrict__ slab_s, const float2 *__restrict__ sl
         a.x += b.x; a.y += b.y;
     }
     for (uint32_t i = 0; i < g; ++i) {
-        const float2 b = slab_r[(size_t)i * n + k];
+        const uint32_t rr = tile_row[i];
+        if (rr == SYM_NONE) continue;
+        const float2 b = slab_r[(size_t)rr * n + k];
         a.x += b.x; a.y += b.y;
     }
     acc_sum[k] = a;

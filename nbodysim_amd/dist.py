@@ -1,12 +1,21 @@
 """One-process-per-GPU sharding of the hot path.
 
-i-particles are independent, so each rank integrates one contiguous block and
-holds a full-n replica of the positions; the only exchange per step is an
-all-gather of the freshly drifted (x, y) blocks.  The collective is
-``torch.distributed.all_gather_into_tensor`` — RCCL over xGMI with the ``nccl``
-backend, gloo on CPU for the tests — writing IN PLACE into the device replica
-the force kernel reads, on the process group's communication stream, while the
-local-tile force of the next step already runs on the compute stream:
+Each rank integrates one contiguous block of particles and holds a full-n replica
+of the positions (double buffered, in torch tensors so the collectives write them
+in place).  The library tells which exchange a handle needs (``nb_shard_protocol``):
+
+NB_SHARD_SYMMETRIC (fp32, eps > 0, large n — the benchmark case).  Every rank
+evaluates a balanced share of the UNORDERED pairs with the symmetric kernel (tiles
+dealt in snake order), which yields a partial acceleration for every particle:
+
+    [compute]  force_sym(my tiles) -> acc_partial[n] | reduce-scatter(sum) -> acc[my block] | kick, drift | all-gather(x,y)
+
+two collectives per step (2 MiB each at N = 262 144, latency-bound), RCCL
+``reduce_scatter_tensor`` / ``all_gather_into_tensor`` over xGMI.
+
+NB_SHARD_ALLGATHER (everything else).  i-particles are independent: the only
+exchange is the all-gather of the drifted (x, y) blocks, overlapped with the
+local-tile force of the next step on the compute stream:
 
     step k:   [compute]  force(local j-block) ......... wait(AG k-1) force(remote) integrate
               [comm   ]  ... all-gather of step k-1's positions ...          \\-> all-gather k
@@ -21,6 +30,8 @@ from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
+
+from . import _lib as L
 
 
 @dataclass(frozen=True)
@@ -90,11 +101,20 @@ class DistributedSimulation:
         # full-n position replicas owned by torch so the collective can write them
         self.pos = [torch.empty((self.plan.n, 2), dtype=dtype, device=self.device) for _ in range(2)]
         self.stream = torch.cuda.Stream(self.device)
+        # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
+        self.acc_full = self.acc_owned = None
+        acc_ptrs = None
+        if precision == "fp32" and world > 1:
+            self.acc_full = torch.zeros((self.plan.n, 2), dtype=torch.float32, device=self.device)
+            self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=torch.float32, device=self.device)
+            acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
         self.sim = Simulation(
             bodies, eps=eps, precision=precision, rsqrt=rsqrt, order=order, device=device_index, j_slices=j_slices,
             i_begin=self.plan.i_begin, i_count=self.plan.i_count, stream=self.stream.cuda_stream,
             pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
+            shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs,
         )
+        self.symmetric = self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
@@ -103,8 +123,28 @@ class DistributedSimulation:
     def frame(self) -> int:
         return self.sim.frame
 
+    def _reduce_accelerations(self) -> None:
+        """Sum the ranks' partial accelerations; every rank keeps its own block."""
+        backend = self.dist.get_backend(self.group)
+        if backend == "nccl":
+            self.dist.reduce_scatter_tensor(self.acc_owned, self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:   # gloo has no reduce-scatter: all-reduce, then keep the owned rows
+            self.dist.all_reduce(self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.acc_owned.copy_(self.acc_full[self.plan.i_begin : self.plan.i_end])
+
     def step(self, dt: Optional[float] = None) -> None:
         """One sharded step; only enqueues (no host sync)."""
+        if self.symmetric:
+            with self.torch.cuda.stream(self.stream):
+                if self._pending is not None:
+                    self._pending.wait()     # every rank's new positions are in the CURRENT replica
+                    self._pending = None
+                self.sim.step_begin(dt)      # symmetric force over my tiles -> partial acceleration of all n
+                self._reduce_accelerations() # ordered after the force on this stream by the process group
+                self.sim.step_finish()       # kick, drift of my block -> NEXT becomes CURRENT
+                self._cur ^= 1
+                self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
+            return
         with self.torch.cuda.stream(self.stream):
             self.sim.step_begin(dt)          # local j-block: overlaps the in-flight all-gather
             if self._pending is not None:

@@ -47,6 +47,9 @@ class Simulation:
         i_count: int = 0,
         stream: Optional[int] = None,
         pos_buffers: Optional[tuple] = None,
+        shard_rank: int = 0,
+        shard_world: int = 0,
+        acc_buffers: Optional[tuple] = None,
     ):
         lib = L.load()
         if bodies.dtype != L.BODY_DTYPE:
@@ -68,6 +71,9 @@ class Simulation:
             p.stream = stream
         if pos_buffers is not None:
             p.pos_buffers[0], p.pos_buffers[1] = pos_buffers
+        p.shard_rank, p.shard_world = shard_rank, shard_world
+        if acc_buffers is not None:
+            p.acc_buffers[0], p.acc_buffers[1] = acc_buffers
         self._lib = lib
         self._params = p
         self._h = lib.nb_create(bodies.ctypes.data, bodies.shape[0], C.byref(p))
@@ -134,6 +140,13 @@ class Simulation:
 
     def pos_buffer(self, which: int = L.NB_POS_CURRENT) -> int:
         return int(self._lib.nb_pos_buffer(self._h, which) or 0)
+
+    @property
+    def shard_protocol(self) -> int:
+        return int(self._lib.nb_shard_protocol(self._h))
+
+    def acc_buffer(self, which: int) -> int:
+        return int(self._lib.nb_acc_buffer(self._h, which) or 0)
 
     @property
     def stream(self) -> int:

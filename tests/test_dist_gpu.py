@@ -49,6 +49,7 @@ def _worker(rank, world, port, backend, n, steps, precision, out_dir):
         sim.advance(steps, 1e-3)
         k1, u1 = sim.energy()
         mine = sim.sync().copy()
+        np.save(Path(out_dir) / f"sym_{rank}.npy", np.array([int(sim.symmetric)]))
         np.save(Path(out_dir) / f"pos_{rank}.npy", mine["pos"])
         np.save(Path(out_dir) / f"vel_{rank}.npy", mine["vel"])
         np.save(Path(out_dir) / f"energy_{rank}.npy", np.array([k0, u0, k1, u1]))
@@ -73,14 +74,18 @@ def _rel(a, b):
     return float(np.max(np.linalg.norm(a.astype(np.float64) - b, axis=1) / np.linalg.norm(b.astype(np.float64), axis=1)))
 
 
-@pytest.mark.parametrize("world,backend,precision", [(1, "nccl", "fp32"), (2, "gloo", "fp32"), (4, "gloo", "fp32"), (2, "gloo", "fp64")])
-def test_distributed_simulation_matches_single_handle(tmp_path, world, backend, precision):
+@pytest.mark.parametrize("world,backend,precision,n,expect_sym", [
+    (1, "nccl", "fp32", 4096, 0), (2, "gloo", "fp32", 4096, 0), (4, "gloo", "fp32", 4096, 0), (2, "gloo", "fp64", 4096, 0),
+    (2, "gloo", "fp32", 32768, 1), (4, "gloo", "fp32", 32768, 1), (1, "nccl", "fp32", 32768, 0), (2, "gloo", "fp64", 32768, 0)])
+def test_distributed_simulation_matches_single_handle(tmp_path, world, backend, precision, n, expect_sym):
     import torch.multiprocessing as mp
-    n, steps = 4096, 6
+    steps = 6
     mp.spawn(_worker, args=(world, _free_port(), backend, n, steps, precision, str(tmp_path)), nprocs=world, join=True)
     pos_ref, vel_ref, e_ref = _reference(n, steps, precision)
     pos = np.concatenate([np.load(tmp_path / f"pos_{r}.npy") for r in range(world)])
     vel = np.concatenate([np.load(tmp_path / f"vel_{r}.npy") for r in range(world)])
+    for r in range(world):   # the symmetric (reduce-scatter) protocol is used exactly where it should be
+        assert int(np.load(tmp_path / f"sym_{r}.npy")[0]) == expect_sym
     tol = 2e-6 if precision == "fp32" else 1e-7   # different slab grouping of the same fp32 sums
     assert _rel(pos, pos_ref) < tol
     assert _rel(vel, vel_ref) < 10 * tol
