@@ -514,7 +514,7 @@ static int launch_force_sym(nb_sim *s)
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    sym_gather<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, s->sym_tile_row_dev, n,
+    sym_gather<<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, s->sym_tile_row_dev, n,
                                                                  s->sym_sharded ? s->acc_full : (float2 *)s->partial);
     HIPCHK(hipGetLastError());
     return NB_OK;

@@ -445,26 +445,42 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 //            + sum over earlier tiles I held here of slab_r[tile_row[I]][k]  (in tile order).
 constexpr uint32_t SYM_NONE = 0xffffffffu;
 
+// 32 particles per workgroup, 8 threads per particle: thread (q, p) adds the rows r = q (mod 8)
+// of particle p's lists in ascending order, the 8 partials are then added in q order — a fixed
+// association whatever the launch, so results are reproducible run to run.
+constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
+
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const float2 *__restrict__ slab_s, const float2 *__restrict__ slab_r,
                 const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row,
                 uint32_t n, float2 *__restrict__ acc_sum)
 {
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
+    __shared__ float2 part[GATHER_Q][GATHER_P];
+    const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
+    const uint32_t k = blockIdx.x * GATHER_P + p;
     float2 a = make_float2(0.f, 0.f);
-    for (uint32_t r = rowbase[g]; r < rowbase[g + 1]; ++r) {
-        const float2 b = slab_s[(size_t)r * SYM_SB + loc];
-        a.x += b.x; a.y += b.y;
+    if (k < n) {
+        const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
+        const uint32_t r0 = rowbase[g], r1 = rowbase[g + 1];
+        for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
+            const float2 b = slab_s[(size_t)r * SYM_SB + loc];
+            a.x += b.x; a.y += b.y;
+        }
+        for (uint32_t i = q; i < g; i += GATHER_Q) {
+            const uint32_t rr = tile_row[i];
+            if (rr == SYM_NONE) continue;
+            const float2 b = slab_r[(size_t)rr * n + k];
+            a.x += b.x; a.y += b.y;
+        }
     }
-    for (uint32_t i = 0; i < g; ++i) {
-        const uint32_t rr = tile_row[i];
-        if (rr == SYM_NONE) continue;
-        const float2 b = slab_r[(size_t)rr * n + k];
-        a.x += b.x; a.y += b.y;
+    part[q][p] = a;
+    __syncthreads();
+    if (q == 0 && k < n) {
+        float2 t = part[0][p];
+#pragma unroll
+        for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][p].x; t.y += part[j][p].y; }
+        acc_sum[k] = t;
     }
-    acc_sum[k] = a;
 }
 
 // ---------------------------------------------------------------------------

@@ -17,7 +17,7 @@ ic = nb.plummer_2d(n, 42)
 
 def run(parts, rank):
     ic_count = n // parts
-    kw = dict(i_begin=rank * ic_count, i_count=ic_count) if parts > 1 else {}
+    kw = dict(i_begin=rank * ic_count, i_count=ic_count, shard_rank=rank, shard_world=parts) if parts > 1 else {}
     with nb.Simulation(ic, eps=0.01, **kw) as sim:
         def go(k):
             if parts == 1:
@@ -36,6 +36,6 @@ def run(parts, rank):
 base, base_k, d = run(1, 0)
 print(f"1 GPU : {base:.3f} ms/step (force kernels {base_k:.3f})  {d}")
 for parts in (2, 4, 8):
-    for rank in sorted({0, parts // 2}):
+    for rank in sorted({0, parts // 2, parts - 1}):
         t, k, d = run(parts, rank)
-        print(f"{parts} ranks, rank {rank}: {t:.3f} ms/step (force kernels {k:.3f}) ideal {base / parts:.3f} -> efficiency {base / parts / t * 100:.1f}%  | {d.split('|')[3]}")
+        print(f"{parts} ranks, rank {rank}: {t:.3f} ms/step (force kernels {k:.3f}) ideal {base / parts:.3f} -> efficiency {base / parts / t * 100:.1f}%  | {'|'.join(d.split('|')[3:5])}")

@@ -63,8 +63,10 @@ for k, d in summary.items():
 
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps({"counters": summary, "derived": derived, "dispatch": meta}, indent=1) + "\n")
 print("pmc summary ->", out / f"{tag}_pmc_summary.json")
+# the dominant force kernel of the run: the symmetric kernel when it ran, else the one-sided tiled kernel
+force_keys = [k for k in derived if "force_sym_f32" in k] or [k for k in derived if "force_tiled_f32" in k]
 for k, x in derived.items():
-    if "force_tiled_f32" in k and "hbm_read_bytes_corrected" in x and "hbm_write_bytes" in x:
+    if k in force_keys[:1] and "hbm_read_bytes_corrected" in x and "hbm_write_bytes" in x:
         t = {"round": tag, "kernel": k, "force_kernel_hbm_bytes_per_launch": x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"],
              "read_bytes_raw_FETCH_SIZE": x["hbm_read_bytes_raw"], "read_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
              "write_bytes_WRITE_SIZE": x["hbm_write_bytes"]}
