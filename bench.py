@@ -84,6 +84,9 @@ def main() -> None:
     ap.add_argument("--rsqrt", default="exact", choices=["exact", "quake"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
+    ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + --share-gpu rehearses the multi-rank path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     args = ap.parse_args()
 
     import torch
@@ -100,6 +103,8 @@ def main() -> None:
     n = args.n
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
     ic = nb.plummer_2d(n, SEED)   # every rank generates the same deterministic ICs
@@ -109,7 +114,10 @@ def main() -> None:
         from nbodysim_amd.dist import DistributedSimulation
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank)
         inner = sim.sim
         advance, wait = sim.advance, sim.wait
@@ -184,9 +192,12 @@ def main() -> None:
             "data": "synthetic (3-D Plummer sphere projected to 2-D, mt19937 seed 42, equal masses, eps=0.01, dt=1e-3)",
             "config": {
                 "workload": f"N={n} {args.precision} direct O(N^2), one MI355X per rank, LDS tile=256" if world == 1 else
-                            f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, all-gather of (x,y) per step",
+                            f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, "
+                            + ("symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step"
+                               if getattr(sim, "symmetric", False) else "all-gather of (x,y) per step overlapped with the local-tile force"),
                 "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled",
                 "parallelism": f"i-block x{world}" if world > 1 else "single GPU",
+                "backend": args.backend if world > 1 else None,
                 "launch": inner.describe(),
             },
             "roofline": {
