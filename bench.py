@@ -208,7 +208,7 @@ def main() -> None:
                 "frac": achieved / (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2),
                 "traffic": traffic,
                 "flop_per_pair": FLOP_PER_PAIR,
-                "kernel": ("force_sym_f32" if "symmetric=1" in inner.describe() else "force_tiled_f32") if args.precision == "fp32" else "force_tiled_f64",
+                "kernel": ("force_sym_" if "symmetric=1" in inner.describe() else "force_tiled_") + ("f32" if args.precision == "fp32" else "f64"),
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
                 "note": "fp32 vector-ALU bound (no dense contraction for MFMA; the f32 MFMA peak equals the vector peak, 157.3 TF); "

@@ -116,10 +116,10 @@ struct nb_sim {
     uint32_t sym_items = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0;
     SymItem *sym_items_dev = nullptr;
     uint32_t *sym_rowbase_dev = nullptr, *sym_tile_row_dev = nullptr;
-    float2 *sym_slab_s = nullptr, *sym_slab_r = nullptr;
+    void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
-    float2 *acc_full = nullptr, *acc_owned = nullptr;   // reduce-scatter input (n) / output (i_count)
+    void *acc_full = nullptr, *acc_owned = nullptr;     // reduce-scatter input (n) / output (i_count), (ax,ay) reals
     bool own_acc = true;
 
     // profiling
@@ -209,12 +209,13 @@ static void plan(nb_sim *s)
 static bool sym_eligible(const nb_sim *s)
 {
     if (getenv("NB_NO_SYMMETRY")) return false;
-    if (s->fp64 || s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
+    if (s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
+    if (s->fp64 && s->p.rsqrt_mode != NB_RSQRT_EXACT) return false;
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
     if (s->n < 8 * (size_t)SYM_SB) return false;
     const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
     const size_t world = s->p.shard_world > 1 ? (size_t)s->p.shard_world : 1;
-    if ((tiles + world - 1) / world * s->n * sizeof(float2) > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
+    if ((tiles + world - 1) / world * s->n * 2 * s->rsz > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
     return true;
 }
 
@@ -274,16 +275,16 @@ static int plan_sym(nb_sim *s)
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&s->sym_tile_row_dev, tile_row.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * sizeof(float2)));
-    HIPCHK(hipMalloc((void **)&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * sizeof(float2)));
+    HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * 2 * s->rsz));
+    HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * 2 * s->rsz));
     HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_tile_row_dev, tile_row.data(), tile_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (s->sym_sharded) {
-        if (s->p.acc_buffers[0]) { s->acc_full = (float2 *)s->p.acc_buffers[0]; s->acc_owned = (float2 *)s->p.acc_buffers[1]; s->own_acc = false; }
+        if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
         else {
-            HIPCHK(hipMalloc((void **)&s->acc_full, (size_t)n * sizeof(float2)));
-            HIPCHK(hipMalloc((void **)&s->acc_owned, s->i_count * sizeof(float2)));
+            HIPCHK(hipMalloc(&s->acc_full, (size_t)n * 2 * s->rsz));
+            HIPCHK(hipMalloc(&s->acc_owned, s->i_count * 2 * s->rsz));
         }
     }
     return NB_OK;
@@ -312,7 +313,7 @@ static int do_upload(nb_sim *s, const nb_body *in)
 {
     // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
     // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_NO_UNIFORM_MASS=1 disables it.
-    s->uniform_mass = s->n > 0 && !getenv("NB_NO_UNIFORM_MASS") && !s->fp64 && s->p.sum_order == NB_SUM_TILED;
+    s->uniform_mass = s->n > 0 && !getenv("NB_NO_UNIFORM_MASS") && s->p.sum_order == NB_SUM_TILED;
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
@@ -500,22 +501,36 @@ static int launch_force_sym(nb_sim *s)
 {
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+    const uint32_t n = (uint32_t)s->n;
+    void *dst = s->sym_sharded ? s->acc_full : s->partial;
+    if (s->fp64) {
+        const double eps2 = (double)s->p.eps * (double)s->p.eps;
+        const double2 *pos = (const double2 *)s->pos[s->cur];
+        const double *mass = (const double *)s->mass;
+        if (s->uniform_mass) force_sym_f64<true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
+        else                 force_sym_f64<false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
+        HIPCHK(hipGetLastError());
+        if (s->prof && prof_end(s, pr)) return NB_EHIP;
+        sym_gather<double2><<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r,
+                                                                                   s->sym_rowbase_dev, s->sym_tile_row_dev, n, (double2 *)dst);
+        HIPCHK(hipGetLastError());
+        return NB_OK;
+    }
     const float eps2 = s->p.eps * s->p.eps;
     const float2 *pos = (const float2 *)s->pos[s->cur];
     const float *mass = (const float *)s->mass;
-    const uint32_t n = (uint32_t)s->n;
+    float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
     const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
     if (s->uniform_mass) {
-        if (quake) force_sym_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, s->um_mass);
-        else       force_sym_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, s->um_mass);
+        if (quake) force_sym_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
+        else       force_sym_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
     } else {
-        if (quake) force_sym_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, 1.0f);
-        else       force_sym_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, s->sym_slab_s, s->sym_slab_r, n, eps2, 1.0f);
+        if (quake) force_sym_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
+        else       force_sym_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    sym_gather<<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>(s->sym_slab_s, s->sym_slab_r, s->sym_rowbase_dev, s->sym_tile_row_dev, n,
-                                                                 s->sym_sharded ? s->acc_full : (float2 *)s->partial);
+    sym_gather<float2><<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
@@ -615,9 +630,14 @@ extern "C" int nb_step_finish(nb_sim *s)
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
         const int nxt = s->cur ^ 1;
         const float dt = s->pending_dt;
-        integrate<float, false><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
-                                                            (float2 *)s->acc, s->acc_owned, 1u, (uint32_t)s->i_begin, ic, dt, dt,
-                                                            s->p.extras, INTEG_KICK | INTEG_DRIFT);
+        if (s->fp64)
+            integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
+                                                                 (double2 *)s->acc, (const double2 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic,
+                                                                 (double)dt, (double)dt, s->p.extras, INTEG_KICK | INTEG_DRIFT);
+        else
+            integrate<float, false><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
+                                                                (float2 *)s->acc, (const float2 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic, dt, dt,
+                                                                s->p.extras, INTEG_KICK | INTEG_DRIFT);
         HIPCHK(hipGetLastError());
         s->cur ^= 1;
         s->frame += 1;
@@ -805,7 +825,7 @@ extern "C" int nb_shard_protocol(const nb_sim *s)
 extern "C" void *nb_acc_buffer(nb_sim *s, int which)
 {
     if (!s || !s->sym_sharded) return nullptr;
-    return which == 0 ? (void *)s->acc_full : (void *)s->acc_owned;
+    return which == 0 ? s->acc_full : s->acc_owned;
 }
 
 extern "C" int nb_dump(nb_sim *s, const char *path)

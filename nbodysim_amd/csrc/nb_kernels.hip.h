@@ -304,6 +304,7 @@ struct SymItem { uint32_t tile, c0, cnt, s_row, r_row, diag, pad0, pad1; };   //
 #define NB_SYM_P 4
 #endif
 constexpr int SYM_P = NB_SYM_P;                          // packed stationary pairs per lane
+constexpr int SYM_UNROLL = NB_SYM_UNROLL;
 constexpr uint32_t SYM_WT = 64 * 2 * SYM_P;              // stationary particles per wave  (512)
 constexpr uint32_t SYM_SB = 4 * SYM_WT;                  // ... per workgroup / block-tile (2048)
 constexpr uint32_t SYM_CH = 64;                          // travelling chunk
@@ -338,7 +339,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
             if (c + 1 < cnt && j < n) { const float2 pj = pos[j]; xn = pj.x; yn = pj.y; if constexpr (!UM) mn = mass[j]; }
         }
         v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};
-#pragma unroll NB_SYM_UNROLL
+#pragma unroll SYM_UNROLL
         for (int step = 0; step < 64; ++step) {
             // positions of the next step do not depend on this step's arithmetic: rotate them early
             const float xr = lane_rot(xq, addr), yr = lane_rot(yq, addr);
@@ -450,36 +451,159 @@ constexpr uint32_t SYM_NONE = 0xffffffffu;
 // association whatever the launch, so results are reproducible run to run.
 constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
 
+template <typename real2>
 __global__ __launch_bounds__(BLOCK)
-void sym_gather(const float2 *__restrict__ slab_s, const float2 *__restrict__ slab_r,
+void sym_gather(const real2 *__restrict__ slab_s, const real2 *__restrict__ slab_r,
                 const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row,
-                uint32_t n, float2 *__restrict__ acc_sum)
+                uint32_t n, real2 *__restrict__ acc_sum)
 {
-    __shared__ float2 part[GATHER_Q][GATHER_P];
+    __shared__ real2 part[GATHER_Q][GATHER_P];
     const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
     const uint32_t k = blockIdx.x * GATHER_P + p;
-    float2 a = make_float2(0.f, 0.f);
+    real2 a; a.x = 0; a.y = 0;
     if (k < n) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
         const uint32_t r0 = rowbase[g], r1 = rowbase[g + 1];
         for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
-            const float2 b = slab_s[(size_t)r * SYM_SB + loc];
+            const real2 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y;
         }
         for (uint32_t i = q; i < g; i += GATHER_Q) {
             const uint32_t rr = tile_row[i];
             if (rr == SYM_NONE) continue;
-            const float2 b = slab_r[(size_t)rr * n + k];
+            const real2 b = slab_r[(size_t)rr * n + k];
             a.x += b.x; a.y += b.y;
         }
     }
     part[q][p] = a;
     __syncthreads();
     if (q == 0 && k < n) {
-        float2 t = part[0][p];
+        real2 t = part[0][p];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][p].x; t.y += part[j][p].y; }
         acc_sum[k] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force_sym_f64 — the symmetric scheme in double precision (BASELINE config 5).
+// Same items, tiles (2048 particles per workgroup) and slabs as force_sym_f32; a lane holds
+// 8 stationary particles as scalars (no packed fp64 exists), the travelling particle and its
+// accumulator are rotated as pairs of 32-bit halves (10 ds_bpermute_b32 per step, 8 with UM).
+// Body, both directions: 2 add + 2 fma + v_rsq_f64 (+5 refinement ops) + 2 mul + 4 fma
+// (+2 mul with individual masses) for 128 ordered interactions per wave.
+// ---------------------------------------------------------------------------
+constexpr int SYM_P64 = 8;    // stationary particles per lane: 64 * 8 = SYM_WT per wave
+__device__ __forceinline__ double rsqrt_f64(double x);
+
+__device__ __forceinline__ double lane_rot64(double v, int addr)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+constexpr double PAD_XY64 = 1.0e150;   // r^2 = 2e300 finite, (1/r)^3 = 3.5e-451 underflows to 0
+
+template <bool UM, bool DIAG>
+__device__ __forceinline__
+void sym_chunks_f64(const double2 *__restrict__ pos, const double *__restrict__ mass,
+                    double2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                    const double (&xi)[SYM_P64], const double (&yi)[SYM_P64], const double (&mi)[SYM_P64],
+                    double (&ax)[SYM_P64], double (&ay)[SYM_P64], double eps2, double um_mass, double2 (*red)[4][64])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    double xq = PAD_XY64, yq = PAD_XY64, mq = 0.0;
+    {
+        const uint32_t j = c0 * SYM_CH + lane;
+        if (j < n) { const double2 pj = pos[j]; xq = pj.x; yq = pj.y; if constexpr (!UM) mq = mass[j]; }
+    }
+    for (uint32_t c = 0; c < cnt; ++c) {
+        double xn = PAD_XY64, yn = PAD_XY64, mn = 0.0;
+        {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (c + 1 < cnt && j < n) { const double2 pj = pos[j]; xn = pj.x; yn = pj.y; if constexpr (!UM) mn = mass[j]; }
+        }
+        double aqx = 0.0, aqy = 0.0;
+        for (int step = 0; step < 64; ++step) {
+            const double xr = lane_rot64(xq, addr), yr = lane_rot64(yq, addr);
+            double mr = 0.0;
+            if constexpr (!UM) mr = lane_rot64(mq, addr);
+#pragma unroll
+            for (int p = 0; p < SYM_P64; ++p) {
+                const double dx = xq - xi[p], dy = yq - yi[p];
+                const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
+                const double inv = rsqrt_f64(r2);
+                const double inv3 = inv * (inv * inv);
+                if constexpr (UM) {
+                    ax[p] = __builtin_fma(inv3, dx, ax[p]);
+                    ay[p] = __builtin_fma(inv3, dy, ay[p]);
+                    if constexpr (!DIAG) { aqx = __builtin_fma(-inv3, dx, aqx); aqy = __builtin_fma(-inv3, dy, aqy); }
+                } else {
+                    const double si = mq * inv3;
+                    ax[p] = __builtin_fma(si, dx, ax[p]);
+                    ay[p] = __builtin_fma(si, dy, ay[p]);
+                    if constexpr (!DIAG) {
+                        const double sj = mi[p] * inv3;
+                        aqx = __builtin_fma(-sj, dx, aqx);
+                        aqy = __builtin_fma(-sj, dy, aqy);
+                    }
+                }
+            }
+            xq = xr; yq = yr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) { aqx = lane_rot64(aqx, addr); aqy = lane_rot64(aqy, addr); }
+        }
+        if constexpr (!DIAG) {
+            double2 r = make_double2(aqx, aqy);
+            if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; }
+            double2 (*rb)[64] = red[c & 1u];
+            rb[w][lane] = r;
+            __syncthreads();
+            if (w == 0) {
+                const uint32_t j = (c0 + c) * SYM_CH + lane;
+                double2 a = rb[0][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn;
+        if constexpr (!UM) mq = mn;
+    }
+}
+
+template <bool UM>
+__global__ __launch_bounds__(BLOCK)
+void force_sym_f64(const double2 *__restrict__ pos, const double *__restrict__ mass,
+                   const SymItem *__restrict__ items,
+                   double2 *__restrict__ slab_s, double2 *__restrict__ slab_r,
+                   uint32_t n, double eps2, double um_mass)
+{
+    static_assert(64 * SYM_P64 == SYM_WT, "fp64 and fp32 symmetric kernels share the tile geometry");
+    __shared__ double2 red[2][4][64];
+    const SymItem it = items[blockIdx.x];
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    double xi[SYM_P64], yi[SYM_P64], mi[SYM_P64], ax[SYM_P64], ay[SYM_P64];
+    uint32_t li[SYM_P64];
+#pragma unroll
+    for (int p = 0; p < SYM_P64; ++p) {
+        li[p] = w * SYM_WT + (uint32_t)p * 64u + lane;
+        const uint32_t g = it.tile * SYM_SB + li[p];
+        xi[p] = PAD_XY64; yi[p] = PAD_XY64; mi[p] = 0.0;
+        if (g < n) { const double2 q = pos[g]; xi[p] = q.x; yi[p] = q.y; if constexpr (!UM) mi[p] = mass[g]; }
+        ax[p] = 0.0; ay[p] = 0.0;
+    }
+    double2 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
+    if (it.diag) sym_chunks_f64<UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    else         sym_chunks_f64<UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    double2 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;
+#pragma unroll
+    for (int p = 0; p < SYM_P64; ++p) {
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
+        out[li[p]] = make_double2(ax[p], ay[p]);
     }
 }
 

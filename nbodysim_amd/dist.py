@@ -104,9 +104,9 @@ class DistributedSimulation:
         # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
         self.acc_full = self.acc_owned = None
         acc_ptrs = None
-        if precision == "fp32" and world > 1:
-            self.acc_full = torch.zeros((self.plan.n, 2), dtype=torch.float32, device=self.device)
-            self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=torch.float32, device=self.device)
+        if world > 1:
+            self.acc_full = torch.zeros((self.plan.n, 2), dtype=dtype, device=self.device)
+            self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=dtype, device=self.device)
             acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
         self.sim = Simulation(
             bodies, eps=eps, precision=precision, rsqrt=rsqrt, order=order, device=device_index, j_slices=j_slices,

@@ -235,6 +235,34 @@ def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt):
     assert drift_sym < 1e-6 * np.abs(m * res["sym"]).sum(0).max()
 
 
+@pytest.mark.parametrize("masses", ["uniform", "individual"])
+def test_symmetric_fp64_kernel_matches_fp64_direct(nbo, masses):
+    n = 20000
+    ic = nb.plummer_2d(n, 12)
+    if masses == "individual":
+        ic["mass"] = (np.random.default_rng(3).uniform(0.5, 1.5, n) / n).astype(np.float32)
+    st = nbo.state_from_bodies(ic, np.float64)
+    res = {}
+    for tag, env in (("sym", None), ("one_sided", "1")):
+        if env:
+            os.environ["NB_NO_SYMMETRY"] = env
+        try:
+            with nb.Simulation(ic, eps=0.02, precision="fp64") as sim:
+                assert f"symmetric={0 if env else 1}" in sim.describe()
+                k, u = sim.energy()
+                sim.advance(4, 1e-3)
+                k1, u1 = sim.energy()
+                res[tag] = (k1 + u1, sim.sync().copy())
+        finally:
+            os.environ.pop("NB_NO_SYMMETRY", None)
+    d = nbo.step_f64(st, f32(0.02), f32(1e-3), 4)
+    e_ref = sum(nbo.energy(d, f32(0.02)))
+    for tag in res:
+        # same trajectory as the CPU fp64 direct sum: total energy to ~1e-11, positions at float output precision
+        assert abs(res[tag][0] - e_ref) < 1e-10 * abs(e_ref), tag
+        assert max_rel(res[tag][1]["pos"], np.stack([d["x"], d["y"]], 1)) < 2e-7, tag
+
+
 # ------------------------------------------------------------------- fp64 ---
 def test_fp64_matches_fp64_direct(gold, nbo):
     flat = gold["ic_plummer_1024"]
