@@ -262,8 +262,13 @@ static int plan_sym(nb_sim *s)
         rowbase[I] = row;
         if (tile_owner(I, world) != rank) continue;
         tile_row[I] = rrow;
+        // diagonal items (tile I against its own chunks, one-sided), cut like the symmetric ones so
+        // that no single workgroup becomes the critical path at small n
         const uint32_t d0 = I * cpt, dcnt = chunks - d0 < cpt ? chunks - d0 : cpt;
-        items.push_back(SymItem{I, d0, dcnt, row++, rrow, 1u, 0u, 0u});       // diagonal item, one-sided
+        for (uint32_t c = 0; c < dcnt; c += L) {
+            const uint32_t cnt = dcnt - c < L ? dcnt - c : L;
+            items.push_back(SymItem{I, d0 + c, cnt, row++, rrow, 1u, 0u, 0u});
+        }
         for (uint32_t c0 = (I + 1) * cpt; c0 < chunks; c0 += L) {
             const uint32_t cnt = chunks - c0 < L ? chunks - c0 : L;
             items.push_back(SymItem{I, c0, cnt, row++, rrow, 0u, 0u, 0u});
@@ -497,12 +502,14 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
 // Force through the symmetric kernel over the items held by this handle.  Unsharded: leaves the
 // summed acceleration in slab 0.  Sharded: leaves this rank's partial acceleration of ALL particles
 // in acc_full (the host reduce-scatters it into acc_owned).
-static int launch_force_sym(nb_sim *s)
+static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
 {
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
     const uint32_t n = (uint32_t)s->n;
     void *dst = s->sym_sharded ? s->acc_full : s->partial;
+    const int nxt = s->cur ^ 1;
+    const int kd = INTEG_KICK | INTEG_DRIFT;
     if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
@@ -511,8 +518,14 @@ static int launch_force_sym(nb_sim *s)
         else                 force_sym_f64<false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
         HIPCHK(hipGetLastError());
         if (s->prof && prof_end(s, pr)) return NB_EHIP;
-        sym_gather<double2><<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r,
-                                                                                   s->sym_rowbase_dev, s->sym_tile_row_dev, n, (double2 *)dst);
+        const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
+        if (fuse_step)
+            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, s->sym_rowbase_dev,
+                                                                  s->sym_tile_row_dev, n, (double2 *)dst, (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt],
+                                                                  (double2 *)s->vel, (double2 *)s->acc, dt, dt, s->p.extras, kd);
+        else
+            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, s->sym_rowbase_dev,
+                                                                   s->sym_tile_row_dev, n, (double2 *)dst, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
         HIPCHK(hipGetLastError());
         return NB_OK;
     }
@@ -530,7 +543,14 @@ static int launch_force_sym(nb_sim *s)
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    sym_gather<float2><<<(n + GATHER_P - 1) / GATHER_P, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst);
+    const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
+    if (fuse_step)
+        sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst,
+                                                             (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
+                                                             (float)dt, (float)dt, s->p.extras, kd);
+    else
+        sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst,
+                                                              nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
@@ -641,6 +661,14 @@ extern "C" int nb_step_finish(nb_sim *s)
         HIPCHK(hipGetLastError());
         s->cur ^= 1;
         s->frame += 1;
+        return NB_OK;
+    }
+    if (s->sym && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT) {
+        // whole system, symmetric kernel: the gather applies the kick and the drift itself
+        if ((rc = launch_force_sym(s, true, (double)s->pending_dt))) return rc;
+        s->cur ^= 1;
+        s->frame += 1;
+        s->acc_valid = false;
         return NB_OK;
     }
     if (two_phase(s)) {

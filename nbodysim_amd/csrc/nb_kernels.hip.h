@@ -36,6 +36,81 @@ enum { RSQ_EXACT = 0, RSQ_QUAKE = 1 };
 // so far away that 1/r^3 = (7e-19)^3 underflows to exactly 0 while r^2 = 2e36 stays finite.
 constexpr float PAD_XY = 1.0e18f;
 
+template <typename real> struct vec2_of;
+template <> struct vec2_of<float> { typedef float2 type; };
+template <> struct vec2_of<double> { typedef double2 type; };
+
+// ---------------------------------------------------------------------------
+// kick_drift_one — Simulation::iterate after attract(), Simulation.hpp:129-163, for ONE owned
+// particle whose summed acceleration is `a`: acc <- a; v += a dt; [clamp :133-137];
+// [soft boundary :140-155]; x_next = x + v dt.  STRICT keeps every operation individually
+// rounded (the reference build has no FMA contraction) for bit parity.
+// flags: INTEG_KICK applies the kick (+extras), INTEG_DRIFT writes pos_next; 0 = store acc only.
+// ---------------------------------------------------------------------------
+enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
+
+template <typename real, bool STRICT>
+__device__ __forceinline__
+void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
+                    const typename vec2_of<real>::type *__restrict__ pos_cur,
+                    typename vec2_of<real>::type *__restrict__ pos_next,
+                    typename vec2_of<real>::type *__restrict__ vel,
+                    typename vec2_of<real>::type *__restrict__ acc,
+                    uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
+{
+    typedef typename vec2_of<real>::type real2;
+    acc[li] = a;
+    if (!(flags & INTEG_KICK)) return;              // acceleration gather only
+    real2 v = vel[li];
+    const real2 x = pos_cur[i_begin + li];
+    if constexpr (STRICT) {
+#pragma clang fp contract(off)
+        v.x += a.x * dt_kick;                       // Simulation.hpp:130-131
+        v.y += a.y * dt_kick;
+    } else {
+        v.x = __builtin_fma(a.x, dt_kick, v.x);
+        v.y = __builtin_fma(a.y, dt_kick, v.y);
+    }
+    if (extras & 1) {                               // Simulation.hpp:133-137
+#pragma clang fp contract(off)
+        const real MAX_VELOCITY = (real)1000.0;
+        const real vm = v.x * v.x + v.y * v.y;
+        if (vm > MAX_VELOCITY * MAX_VELOCITY) {
+            const real scale = MAX_VELOCITY / sqrt(vm);
+            v.x *= scale; v.y *= scale;
+        }
+    }
+    if (extras & 2) {                               // Simulation.hpp:140-155
+#pragma clang fp contract(off)
+        const real SOFT_BOUNDARY = (real)80000.0;   // 100000.0f * 0.8f
+        const real d2 = x.x * x.x + x.y * x.y;
+        if (d2 > SOFT_BOUNDARY * SOFT_BOUNDARY) {
+            const real dist = sqrt(d2);
+            const real ratio = dist / SOFT_BOUNDARY;
+            const real force = (real)0.9f * exp(ratio - (real)1.0);
+            const real k = (real)-1.0 / dist;
+            const real fdt = force * dt_kick;
+            v.x += (x.x * k) * fdt;
+            v.y += (x.y * k) * fdt;
+            v.x *= (real)0.9995f;
+            v.y *= (real)0.9995f;
+        }
+    }
+    vel[li] = v;
+    if (flags & INTEG_DRIFT) {
+        real2 xn;
+        if constexpr (STRICT) {
+#pragma clang fp contract(off)
+            xn.x = x.x + v.x * dt_drift;            // Simulation.hpp:161-162
+            xn.y = x.y + v.y * dt_drift;
+        } else {
+            xn.x = __builtin_fma(v.x, dt_drift, x.x);
+            xn.y = __builtin_fma(v.y, dt_drift, x.y);
+        }
+        pos_next[i_begin + li] = xn;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Block -> (i_tile, j_slice) decode.  Workgroups are dealt round-robin over the
 // 8 XCDs (b % 8 shares an XCD, MI355X_MICROARCH §Workgroup dispatch): slices
@@ -451,12 +526,22 @@ constexpr uint32_t SYM_NONE = 0xffffffffu;
 // association whatever the launch, so results are reproducible run to run.
 constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
 
-template <typename real2>
+// FUSE: the summed acceleration goes straight into kick_drift_one (whole-system handles: the owned
+// block is everything), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum
+// (sharded ranks: the partial of every particle, to be reduce-scattered).
+template <typename real, bool FUSE>
 __global__ __launch_bounds__(BLOCK)
-void sym_gather(const real2 *__restrict__ slab_s, const real2 *__restrict__ slab_r,
+void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
+                const typename vec2_of<real>::type *__restrict__ slab_r,
                 const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row,
-                uint32_t n, real2 *__restrict__ acc_sum)
+                uint32_t n, typename vec2_of<real>::type *__restrict__ acc_sum,
+                const typename vec2_of<real>::type *__restrict__ pos_cur,
+                typename vec2_of<real>::type *__restrict__ pos_next,
+                typename vec2_of<real>::type *__restrict__ vel,
+                typename vec2_of<real>::type *__restrict__ acc,
+                real dt_kick, real dt_drift, int extras, int flags)
 {
+    typedef typename vec2_of<real>::type real2;
     __shared__ real2 part[GATHER_Q][GATHER_P];
     const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
     const uint32_t k = blockIdx.x * GATHER_P + p;
@@ -481,7 +566,8 @@ void sym_gather(const real2 *__restrict__ slab_s, const real2 *__restrict__ slab
         real2 t = part[0][p];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][p].x; t.y += part[j][p].y; }
-        acc_sum[k] = t;
+        if constexpr (FUSE) kick_drift_one<real, false>(t, k, pos_cur, pos_next, vel, acc, 0u, dt_kick, dt_drift, extras, flags);
+        else acc_sum[k] = t;
     }
 }
 
@@ -756,11 +842,6 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
 // flags: INTEG_KICK applies the kick (+extras), INTEG_DRIFT writes pos_next;
 // flags = 0 only gathers the slabs into acc (nb_accelerations, KDK bootstrap).
 // ---------------------------------------------------------------------------
-enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
-
-template <typename real> struct vec2_of;
-template <> struct vec2_of<float> { typedef float2 type; };
-template <> struct vec2_of<double> { typedef double2 type; };
 
 template <typename real, bool STRICT>
 __global__ __launch_bounds__(BLOCK)
@@ -780,56 +861,7 @@ void integrate(const typename vec2_of<real>::type *__restrict__ pos_cur,
         const real2 b = partial[(size_t)s * i_count + li];
         a.x += b.x; a.y += b.y;
     }
-    acc[li] = a;
-    if (!(flags & INTEG_KICK)) return;              // acceleration gather only
-    real2 v = vel[li];
-    const real2 x = pos_cur[i_begin + li];
-    if constexpr (STRICT) {
-#pragma clang fp contract(off)
-        v.x += a.x * dt_kick;                       // Simulation.hpp:130-131
-        v.y += a.y * dt_kick;
-    } else {
-        v.x = __builtin_fma(a.x, dt_kick, v.x);
-        v.y = __builtin_fma(a.y, dt_kick, v.y);
-    }
-    if (extras & 1) {                               // Simulation.hpp:133-137
-#pragma clang fp contract(off)
-        const real MAX_VELOCITY = (real)1000.0;
-        const real vm = v.x * v.x + v.y * v.y;
-        if (vm > MAX_VELOCITY * MAX_VELOCITY) {
-            const real scale = MAX_VELOCITY / sqrt(vm);
-            v.x *= scale; v.y *= scale;
-        }
-    }
-    if (extras & 2) {                               // Simulation.hpp:140-155
-#pragma clang fp contract(off)
-        const real SOFT_BOUNDARY = (real)80000.0;   // 100000.0f * 0.8f
-        const real d2 = x.x * x.x + x.y * x.y;
-        if (d2 > SOFT_BOUNDARY * SOFT_BOUNDARY) {
-            const real dist = sqrt(d2);
-            const real ratio = dist / SOFT_BOUNDARY;
-            const real force = (real)0.9f * exp(ratio - (real)1.0);
-            const real k = (real)-1.0 / dist;
-            const real fdt = force * dt_kick;
-            v.x += (x.x * k) * fdt;
-            v.y += (x.y * k) * fdt;
-            v.x *= (real)0.9995f;
-            v.y *= (real)0.9995f;
-        }
-    }
-    vel[li] = v;
-    if (flags & INTEG_DRIFT) {
-        real2 xn;
-        if constexpr (STRICT) {
-#pragma clang fp contract(off)
-            xn.x = x.x + v.x * dt_drift;            // Simulation.hpp:161-162
-            xn.y = x.y + v.y * dt_drift;
-        } else {
-            xn.x = __builtin_fma(v.x, dt_drift, x.x);
-            xn.y = __builtin_fma(v.y, dt_drift, x.y);
-        }
-        pos_next[i_begin + li] = xn;
-    }
+    kick_drift_one<real, STRICT>(a, li, pos_cur, pos_next, vel, acc, i_begin, dt_kick, dt_drift, extras, flags);
 }
 
 // ---------------------------------------------------------------------------
