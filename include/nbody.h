@@ -42,6 +42,10 @@ typedef struct nb_vec2 {
     float _pad[2];
 } nb_vec2;
 
+/* z component of a 3-D handle (nb_params.dims = 3): the 8 bytes of padding that follow y in the
+ * reference's alignas(16) Vec2 (Vec2.hpp:17-20). */
+#define NB_Z(v) ((v)._pad[0])
+
 typedef struct nb_body {
     nb_vec2 pos;     /* offset  0  Body::pos    */
     nb_vec2 vel;     /* offset 16  Body::vel    */
@@ -117,6 +121,10 @@ typedef struct nb_params {
                               of every particle (reduce-scatter input), [1] i_count*(ax,ay) =
                               the summed acceleration of the owned block (its output);
                               NULL = allocated by the library */
+    int32_t  dims;         /* 2 (default, the reference) or 3: build extension — z of
+                              pos / vel / acc lives in the first padding float of each vector
+                              (macro NB_Z), sizeof of a body stays 64; fp32, tiled, unsharded only */
+    int32_t  reserved0;
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
@@ -222,6 +230,12 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *                        of the owned block; host all-gathers positions before the next begin. */
 enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2 };
 int   nb_shard_protocol(const nb_sim *s);
+/* Exchange for a host that drives SEVERAL sharded handles from one process (e.g. one per GPU of
+ * the node, no RCCL): every handle's owned block of its CURRENT replica is copied into the CURRENT
+ * replica of every other handle (peer copies; the handles may sit on different devices).  Call it
+ * between nb_step_finish and the next nb_step_finish of NB_SHARD_ALLGATHER handles; it waits for
+ * the handles' enqueued work and returns when the copies are done. */
+int   nb_exchange_positions(nb_sim *const *sims, int count);
 void *nb_acc_buffer(nb_sim *s, int which);   /* 0: full-n partial, 1: owned block sum (NULL if unused) */
 int   nb_step_begin(nb_sim *s, float dt);
 int   nb_step_finish(nb_sim *s);
@@ -243,6 +257,8 @@ int nb_describe(nb_sim *s, char *buf, size_t buflen);
  * Aarseth-Henon-Wielen sampling, r <= 20) projected on (x,y),(vx,vy); equal
  * masses 1/n, radius 0, acc 0.  mt19937(seed) raw outputs mapped (u+0.5)/2^32. */
 int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed);
+/* The same sample without the projection: a true 3-D Plummer sphere (z in NB_Z) for dims = 3. */
+int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);

@@ -7,21 +7,25 @@ the tests and ``bench.py``.  Importing the package does not load the library;
 the first use does, and raises if it has not been built.
 """
 from ._lib import (  # noqa: F401
+    BODY3_DTYPE,
     BODY_DTYPE,
     NBodyError,
     bodies_array,
     load,
     plummer_2d,
+    plummer_3d,
 )
 from .simulation import Simulation, read_bodies, write_bodies  # noqa: F401
 
 __all__ = [
+    "BODY3_DTYPE",
     "BODY_DTYPE",
     "NBodyError",
     "Simulation",
     "bodies_array",
     "load",
     "plummer_2d",
+    "plummer_3d",
     "read_bodies",
     "write_bodies",
 ]

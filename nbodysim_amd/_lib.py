@@ -40,6 +40,17 @@ BODY_DTYPE = np.dtype(
 )
 
 
+#: the same 64 bytes seen by a dims = 3 handle: z of pos / vel / acc in the first padding float
+BODY3_DTYPE = np.dtype(
+    {
+        "names": ["pos", "vel", "acc", "mass", "radius"],
+        "formats": [(np.float32, 3), (np.float32, 3), (np.float32, 3), np.float32, np.float32],
+        "offsets": [0, 16, 32, 48, 52],
+        "itemsize": 64,
+    }
+)
+
+
 class NBodyError(RuntimeError):
     """Raised for every non-zero status / NULL handle coming out of the C ABI."""
 
@@ -67,6 +78,8 @@ class nb_params(C.Structure):
         ("shard_rank", C.c_int32),
         ("shard_world", C.c_int32),
         ("acc_buffers", C.c_void_p * 2),
+        ("dims", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -97,11 +110,13 @@ PROTOTYPES = {
     "nb_pos_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_stream": (C.c_void_p, [C.c_void_p]),
     "nb_shard_protocol": (C.c_int, [C.c_void_p]),
+    "nb_exchange_positions": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_acc_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),
@@ -151,6 +166,13 @@ def bodies_array(n: int) -> np.ndarray:
     """Zero-initialised array of n 64-byte Body records (padding zero)."""
     raw = np.zeros(n * BODY_DTYPE.itemsize, dtype=np.uint8)
     return raw.view(BODY_DTYPE)
+
+
+def plummer_3d(n: int, seed: int = 42) -> np.ndarray:
+    """True 3-D Plummer sphere; view it with ``.view(BODY3_DTYPE)`` to reach z."""
+    out = bodies_array(n)
+    check("nb_plummer_3d", load().nb_plummer_3d(out.ctypes.data, n, seed))
+    return out
 
 
 def plummer_2d(n: int, seed: int = 42) -> np.ndarray:

@@ -9,6 +9,7 @@
 #include "nbody.h"
 #include "nb_internal.h"
 #include "nb_kernels.hip.h"
+#include "nb_kernels3d.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -85,7 +86,9 @@ struct nb_sim {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool fp64 = false;
+    bool dims3 = false;        // 3-D variant: float4 {x,y,z,m} positions, float4 velocities / accelerations / slabs
     size_t rsz = 4;            // sizeof(real)
+    size_t esz = 8;            // bytes of one position / velocity / acceleration / slab element
 
     void *pos[2] = {nullptr, nullptr};
     bool own_pos = true;
@@ -215,7 +218,7 @@ static bool sym_eligible(const nb_sim *s)
     if (s->n < 8 * (size_t)SYM_SB) return false;
     const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
     const size_t world = s->p.shard_world > 1 ? (size_t)s->p.shard_world : 1;
-    if ((tiles + world - 1) / world * s->n * 2 * s->rsz > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
+    if ((tiles + world - 1) / world * s->n * s->esz > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
     return true;
 }
 
@@ -280,16 +283,16 @@ static int plan_sym(nb_sim *s)
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&s->sym_tile_row_dev, tile_row.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * 2 * s->rsz));
-    HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * 2 * s->rsz));
+    HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
+    HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * s->esz));
     HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_tile_row_dev, tile_row.data(), tile_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (s->sym_sharded) {
         if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
         else {
-            HIPCHK(hipMalloc(&s->acc_full, (size_t)n * 2 * s->rsz));
-            HIPCHK(hipMalloc(&s->acc_owned, s->i_count * 2 * s->rsz));
+            HIPCHK(hipMalloc(&s->acc_full, (size_t)n * s->esz));
+            HIPCHK(hipMalloc(&s->acc_owned, s->i_count * s->esz));
         }
     }
     return NB_OK;
@@ -326,7 +329,10 @@ static int do_upload(nb_sim *s, const nb_body *in)
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
     for (int b = 0; b < 2; ++b) {
-        if (s->fp64)
+        if (s->dims3)
+            unpack_bodies3<<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (float4 *)s->pos[b], (float4 *)s->vel, (float4 *)s->acc, s->radius,
+                                                       (uint32_t)s->i_begin, (uint32_t)s->i_count);
+        else if (s->fp64)
             unpack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (double2 *)s->pos[b], (double *)s->mass,
                                                              (double2 *)s->vel, (double2 *)s->acc, s->radius,
                                                              (uint32_t)s->i_begin, (uint32_t)s->i_count);
@@ -363,6 +369,13 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
+    if (p.dims == 0) p.dims = 2;
+    if (p.dims != 2 && p.dims != 3) { nb_set_error("nb_create: dims must be 2 or 3"); return nullptr; }
+    if (p.dims == 3 && (p.precision != NB_FP32 || p.sum_order != NB_SUM_TILED || p.extras != 0 ||
+                        (p.i_count != 0 && p.i_count != n) || p.shard_world > 1)) {
+        nb_set_error("nb_create: dims = 3 supports fp32, tiled sum, no extras, unsharded handles");
+        return nullptr;
+    }
     if (p.i_count == 0) { p.i_begin = 0; p.i_count = n; }
     if (p.i_begin + p.i_count > n) { nb_set_error("nb_create: owned block [%llu,+%llu) exceeds n=%zu", (unsigned long long)p.i_begin, (unsigned long long)p.i_count, n); return nullptr; }
     if ((p.pos_buffers[0] == nullptr) != (p.pos_buffers[1] == nullptr)) { nb_set_error("nb_create: give both pos_buffers or none"); return nullptr; }
@@ -380,6 +393,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->p = p; s->n = n; s->i_begin = (size_t)p.i_begin; s->i_count = (size_t)p.i_count; s->dev = dev;
     s->fp64 = p.precision == NB_FP64;
     s->rsz = s->fp64 ? 8 : 4;
+    s->dims3 = p.dims == 3;
+    s->esz = s->dims3 ? sizeof(float4) : 2 * s->rsz;
 
     auto fail = [&](const char *what, hipError_t e) -> nb_sim * {
         nb_set_error("nb_create: %s: %s", what, hipGetErrorString(e));
@@ -395,7 +410,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     else { if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e); s->own_stream = true; }
 
     plan(s);
-    const size_t r2 = 2 * s->rsz;
+    const size_t r2 = s->esz;
     if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; }
     else {
         if ((e = hipMalloc(&s->pos[0], n * r2)) != hipSuccess) return fail("hipMalloc pos", e);
@@ -510,6 +525,30 @@ static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
     void *dst = s->sym_sharded ? s->acc_full : s->partial;
     const int nxt = s->cur ^ 1;
     const int kd = INTEG_KICK | INTEG_DRIFT;
+    if (s->dims3) {
+        const float eps2 = s->p.eps * s->p.eps;
+        const float4 *pos = (const float4 *)s->pos[s->cur];
+        float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
+        const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
+        if (s->uniform_mass) {
+            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
+            else       force_sym3_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
+        } else {
+            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
+            else       force_sym3_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
+        }
+        HIPCHK(hipGetLastError());
+        if (s->prof && prof_end(s, pr)) return NB_EHIP;
+        const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
+        if (fuse_step)
+            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float4 *)dst, pos, (float4 *)s->pos[nxt],
+                                                           (float4 *)s->vel, (float4 *)s->acc, (float)dt, (float)dt, kd);
+        else
+            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float4 *)dst, nullptr, nullptr,
+                                                            nullptr, nullptr, 0.f, 0.f, 0);
+        HIPCHK(hipGetLastError());
+        return NB_OK;
+    }
     if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
@@ -563,6 +602,28 @@ static int launch_force(nb_sim *s, const ForceJob &j)
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
     const bool guard = s->p.eps == 0.0f;
     const uint32_t ic = (uint32_t)s->i_count;
+    if (s->dims3) {
+        const float eps2 = s->p.eps * s->p.eps;
+        const uint32_t grid = grid_blocks(j.i_tiles, j.js);
+        float4 *out = (float4 *)s->partial + (size_t)j.slab0 * s->i_count;
+        const float4 *pos = (const float4 *)s->pos[s->cur];
+        const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE, um = s->uniform_mass && !guard;
+#define NB_LAUNCH3(PP, RQ, GD, UMM)                                                                                   \
+        force_tiled3_f32<PP, RQ, GD, 8, UMM><<<grid, BLOCK, 0, s->stream>>>(pos, out, (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, \
+                                                                            j.js, j.i_tiles, eps2, um ? s->um_mass : 1.0f)
+#define NB_DISPATCH3(PP)                                                                                              \
+        do {                                                                                                          \
+            if (guard)      { if (quake) NB_LAUNCH3(PP, RSQ_QUAKE, true, false); else NB_LAUNCH3(PP, RSQ_EXACT, true, false); }   \
+            else if (um)    { if (quake) NB_LAUNCH3(PP, RSQ_QUAKE, false, true); else NB_LAUNCH3(PP, RSQ_EXACT, false, true); }   \
+            else            { if (quake) NB_LAUNCH3(PP, RSQ_QUAKE, false, false); else NB_LAUNCH3(PP, RSQ_EXACT, false, false); } \
+        } while (0)
+        if (j.P == 4) NB_DISPATCH3(4); else if (j.P == 2) NB_DISPATCH3(2); else NB_DISPATCH3(1);
+#undef NB_DISPATCH3
+#undef NB_LAUNCH3
+        HIPCHK(hipGetLastError());
+        if (s->prof && prof_end(s, pr)) return NB_EHIP;
+        return NB_OK;
+    }
     if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         if (j.P == 2) { if (guard) launch_tiled_f64<2, true>(s, j, eps2); else launch_tiled_f64<2, false>(s, j, eps2); }
@@ -601,7 +662,10 @@ static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double d
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     const bool strict = s->p.sum_order == NB_SUM_SEQUENTIAL;
     const int nxt = s->cur ^ 1;
-    if (s->fp64)
+    if (s->dims3)
+        integrate3<<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                               (const float4 *)s->partial, nslabs, (uint32_t)s->i_begin, ic, (float)dt_kick, (float)dt_drift, flags);
+    else if (s->fp64)
         integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
                                                              (double2 *)s->acc, (const double2 *)s->partial, nslabs,
                                                              (uint32_t)s->i_begin, ic, dt_kick, dt_drift, s->p.extras, flags);
@@ -694,7 +758,7 @@ static int step_kdk(nb_sim *s, double dt)
         if ((rc = launch_integrate(s, s->slabs_all, 0.0, 0.0, 0))) return rc;   // acc <- slabs only
     } else {
         // acc already holds a(x_n): re-present it as the single slab 0
-        HIPCHK(hipMemcpyAsync(s->partial, s->acc, s->i_count * 2 * s->rsz, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->partial, s->acc, s->i_count * s->esz, hipMemcpyDeviceToDevice, s->stream));
     }
     // half kick + drift (acc from slab(s)), then force at x_{n+1} and the second half kick
     if ((rc = launch_integrate(s, s->acc_valid ? 1 : s->slabs_all, 0.5 * dt, dt, INTEG_KICK | INTEG_DRIFT))) return rc;
@@ -782,7 +846,10 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
     const bool direct = is_pinned_host(out);
     if (!direct && ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
-    if (s->fp64)
+    if (s->dims3)
+        pack_bodies3<<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float4 *)s->pos[s->cur], (const float4 *)s->vel, (const float4 *)s->acc,
+                                                 s->radius, (uint32_t)s->i_begin, ic);
+    else if (s->fp64)
         pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double2 *)s->pos[s->cur], (const double *)s->mass,
                                                         (const double2 *)s->vel, (const double2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
     else
@@ -798,6 +865,7 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
 extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
 {
     if (!s || !out_xy) { nb_set_error("nb_sync_positions: NULL argument"); return NB_EINVAL; }
+    if (s->dims3) { nb_set_error("nb_sync_positions: 2-D handles only (use nb_sync for dims = 3)"); return NB_EINVAL; }
     if (bind(s)) return NB_EHIP;
     if (ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
@@ -820,7 +888,10 @@ extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
     if (bind(s)) return NB_EHIP;
     const uint32_t g = (uint32_t)s->ered_blocks;
     const double eps2 = (double)s->p.eps * (double)s->p.eps;
-    if (s->fp64)
+    if (s->dims3)
+        energy_partials3<<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (const float4 *)s->vel, (uint32_t)s->n,
+                                                     (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2, s->ered_dev, s->ered_dev + g);
+    else if (s->fp64)
         energy_partials<double><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (const double *)s->mass, (const double2 *)s->vel,
                                                             (uint32_t)s->n, (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2,
                                                             s->ered_dev, s->ered_dev + g);
@@ -845,6 +916,35 @@ extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
 extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
 extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
+{
+    if (!sims || count < 1) { nb_set_error("nb_exchange_positions: no handles"); return NB_EINVAL; }
+    for (int a = 0; a < count; ++a) {
+        if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz || sims[a]->sym_sharded) {
+            nb_set_error("nb_exchange_positions: handles must shard the same system with the all-gather protocol");
+            return NB_EINVAL;
+        }
+        if (bind(sims[a])) return NB_EHIP;
+        HIPCHK(hipStreamSynchronize(sims[a]->stream));           // owner's new block is complete
+    }
+    for (int o = 0; o < count; ++o) {
+        const nb_sim *own = sims[o];
+        const char *src = (const char *)own->pos[own->cur] + own->i_begin * own->esz;
+        for (int d = 0; d < count; ++d) {
+            if (d == o) continue;
+            nb_sim *dst = sims[d];
+            if (bind(dst)) return NB_EHIP;
+            HIPCHK(hipMemcpyPeerAsync((char *)dst->pos[dst->cur] + own->i_begin * own->esz, dst->dev, src, own->dev,
+                                      own->i_count * own->esz, dst->stream));
+        }
+    }
+    for (int a = 0; a < count; ++a) {
+        if (bind(sims[a])) return NB_EHIP;
+        HIPCHK(hipStreamSynchronize(sims[a]->stream));
+    }
+    return NB_OK;
+}
+
 extern "C" int nb_shard_protocol(const nb_sim *s)
 {
     if (!s || s->i_count == s->n) return NB_SHARD_NONE;
@@ -894,9 +994,9 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const ForceJob &a = s->job_all;
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
-             "n=%zu owned=[%zu,+%zu) %s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
+             "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
              "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u | CUs=%d",
-             s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32",
+             s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,

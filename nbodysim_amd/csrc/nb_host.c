@@ -49,9 +49,14 @@ static double mt_u01(nb_mt *g) { return ((double)mt_next(g) + 0.5) * (1.0 / 4294
 
 /* 3-D Plummer model, Aarseth, Henon & Wielen (1974) sampling, a = M = G = 1,
  * truncated at r <= 20, projected on the (x,y) plane. */
-int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed)
+static int plummer(nb_body *out, size_t n, uint32_t seed, int dims);
+
+int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed) { return plummer(out, n, seed, 2); }
+int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed) { return plummer(out, n, seed, 3); }
+
+static int plummer(nb_body *out, size_t n, uint32_t seed, int dims)
 {
-    if (!out && n) { nb_set_error("nb_plummer_2d: out is NULL"); return NB_EINVAL; }
+    if (!out && n) { nb_set_error("nb_plummer: out is NULL"); return NB_EINVAL; }
     nb_mt g;
     mt_seed(&g, seed);
     const double two_pi = 6.283185307179586476925286766559;
@@ -81,6 +86,7 @@ int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed)
         memset(&out[i], 0, sizeof(nb_body));
         out[i].pos.x = (float)px; out[i].pos.y = (float)py;
         out[i].vel.x = (float)vx; out[i].vel.y = (float)vy;
+        if (dims == 3) { NB_Z(out[i].pos) = (float)z; NB_Z(out[i].vel) = (float)w; }
         out[i].mass = mass;
         out[i].radius = 0.0f;
     }
@@ -98,7 +104,8 @@ typedef struct nb_file_header {
     float    dt;
     int32_t  precision;
     int32_t  rsqrt_mode;
-    uint8_t  pad[16];
+    int32_t  dims;          /* 0 or 2: planar (the reference); 3: z kept in the first padding float */
+    uint8_t  pad[12];
 } nb_file_header;
 
 _Static_assert(sizeof(nb_file_header) == 64, "dump header is 64 bytes");
@@ -119,7 +126,9 @@ int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t 
     if (params) {
         h.eps = params->eps; h.dt = params->dt;
         h.precision = params->precision; h.rsqrt_mode = params->rsqrt_mode;
+        h.dims = params->dims;
     }
+    const int keep_z = h.dims == 3;
     int rc = NB_OK;
     if (fwrite(&h, sizeof h, 1, f) != 1) rc = NB_EIO;
     /* records are written with padding forced to zero, whatever the caller holds */
@@ -135,6 +144,7 @@ int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t 
             buf[k].vel.x = b->vel.x; buf[k].vel.y = b->vel.y;
             buf[k].acc.x = b->acc.x; buf[k].acc.y = b->acc.y;
             buf[k].mass = b->mass;   buf[k].radius = b->radius;
+            if (keep_z) { NB_Z(buf[k].pos) = NB_Z(b->pos); NB_Z(buf[k].vel) = NB_Z(b->vel); NB_Z(buf[k].acc) = NB_Z(b->acc); }
         }
         if (fwrite(buf, sizeof(nb_body), c, f) != c) rc = NB_EIO;
     }
@@ -170,6 +180,7 @@ int nb_read_header(const char *path, size_t *n, uint64_t *frame, nb_params *para
         nb_params_default(params);
         params->eps = h.eps; params->dt = h.dt;
         params->precision = h.precision; params->rsqrt_mode = h.rsqrt_mode;
+        params->dims = h.dims == 3 ? 3 : 2;
     }
     return NB_OK;
 }

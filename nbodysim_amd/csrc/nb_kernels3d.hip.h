@@ -1,0 +1,399 @@
+// nb_kernels3d.hip.h — the 3-D variant of the hot path (build extension).
+//
+// The reference is strictly 2-D (`Vec2`), but each `alignas(16) Vec2 {float x, y;}` carries 8 bytes
+// of padding right after y (Nbodysim/headers/Vec2.hpp:17-20), so z fits at offset +8 of pos / vel /
+// acc without moving x, y or changing sizeof(Body) = 64 (Body.hpp:6-13).  With nb_params.dims = 3
+// the library reads and writes those slots and evaluates the same softened force with a third
+// component (20 algorithmic flop per pair instead of 14).  There is no reference arithmetic to be
+// bit-exact with here: parity is against the fp64 restatement only ("parity unpinned").
+//
+// Device layout: positions as float4 {x, y, z, m} (one 16-byte load per particle; the mass rides
+// along), velocities / accelerations / slab rows as float4 {·, ·, ·, 0}.
+// Kernels mirror the 2-D ones of nb_kernels.hip.h:
+//   force_sym3_f32    symmetric (Newton's third law) fast path, lane-rotated travelling particles
+//   force_tiled3_f32  one-sided LDS-tiled kernel (small n, eps = 0, cross-check)
+//   sym_gather3 / integrate3 / pack3 / unpack3 / energy3
+#pragma once
+#include "nb_kernels.hip.h"
+
+namespace nbk {
+
+// ---------------------------------------------------------------------------
+// kick/drift for one particle, 3 components (the 2-D extras — velocity clamp, soft
+// boundary — are defined by the reference in the plane only and are not applied).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__
+void kick_drift_one3(float4 a, uint32_t li, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
+                     float4 *__restrict__ vel, float4 *__restrict__ acc, uint32_t i_begin,
+                     float dt_kick, float dt_drift, int flags)
+{
+    a.w = 0.f;
+    acc[li] = a;
+    if (!(flags & INTEG_KICK)) return;
+    float4 v = vel[li];
+    const float4 x = pos_cur[i_begin + li];
+    v.x = __builtin_fmaf(a.x, dt_kick, v.x);
+    v.y = __builtin_fmaf(a.y, dt_kick, v.y);
+    v.z = __builtin_fmaf(a.z, dt_kick, v.z);
+    vel[li] = v;
+    if (flags & INTEG_DRIFT) {
+        float4 xn;
+        xn.x = __builtin_fmaf(v.x, dt_drift, x.x);
+        xn.y = __builtin_fmaf(v.y, dt_drift, x.y);
+        xn.z = __builtin_fmaf(v.z, dt_drift, x.z);
+        xn.w = x.w;                                  // the mass travels with the position
+        pos_next[i_begin + li] = xn;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK)
+void integrate3(const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next, float4 *__restrict__ vel,
+                float4 *__restrict__ acc, const float4 *__restrict__ partial, uint32_t nslabs,
+                uint32_t i_begin, uint32_t i_count, float dt_kick, float dt_drift, int flags)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    float4 a = partial[li];
+    for (uint32_t s = 1; s < nslabs; ++s) {
+        const float4 b = partial[(size_t)s * i_count + li];
+        a.x += b.x; a.y += b.y; a.z += b.z;
+    }
+    kick_drift_one3(a, li, pos_cur, pos_next, vel, acc, i_begin, dt_kick, dt_drift, flags);
+}
+
+// ---------------------------------------------------------------------------
+// force_tiled3_f32 — one-sided, LDS-tiled (the 3-D twin of force_tiled_f32, WS = 4).
+// Tile entries are the position records themselves: float4 {x, y, z, m}.
+// ---------------------------------------------------------------------------
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM>
+__global__ __launch_bounds__(BLOCK)
+void force_tiled3_f32(const float4 *__restrict__ pos, float4 *__restrict__ partial,
+                      uint32_t i_begin, uint32_t i_count, uint32_t j_begin, uint32_t j_end,
+                      uint32_t js, uint32_t i_tiles, float eps2, float um_mass)
+{
+    constexpr int WS = 4;
+    constexpr uint32_t LANES_I = BLOCK / WS, IT = LANES_I * 2 * P, JW = TJ / WS;
+    constexpr uint32_t RED = (WS - 1) * P * LANES_I * 2;      // two float4 per (p, lane): 6 sums in 8 slots
+    constexpr uint32_t SMEM = 2 * TJ > RED ? 2 * TJ : RED;
+    __shared__ v4f smem[SMEM];
+    v4f (*tile)[TJ] = reinterpret_cast<v4f (*)[TJ]>(smem);
+
+    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
+    if (!tm.valid) return;
+    const uint32_t t = threadIdx.x, lane_i = t % LANES_I, w = t / LANES_I;
+    const uint32_t jn = j_end - j_begin;
+    const uint32_t slice_len = (((jn + js - 1) / js + TJ - 1) / TJ) * TJ;
+    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
+    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
+
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+    uint32_t li[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        li[p] = tm.i_tile * IT + (uint32_t)p * (LANES_I * 2) + 2u * lane_i;
+        const float4 p0 = pos[i_begin + min(li[p], i_count - 1)], p1 = pos[i_begin + min(li[p] + 1, i_count - 1)];
+        xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; zi[p] = (v2f){p0.z, p1.z};
+        ax[p] = ay[p] = az[p] = (v2f){0.f, 0.f};
+    }
+    const v2f e2 = {eps2, eps2};
+    const uint32_t ntiles = (s1 - s0 + TJ - 1) / TJ;
+    const v4f pad = {PAD_XY, PAD_XY, PAD_XY, 0.f};
+    {
+        const uint32_t j = s0 + t;
+        v4f q = pad;
+        if (j < s1) { const float4 r = pos[j]; q = (v4f){r.x, r.y, r.z, r.w}; }
+        tile[0][t] = q;
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < ntiles; ++it) {
+        v4f qn = pad;
+        const uint32_t jn1 = s0 + (it + 1) * TJ + t;
+        if (jn1 < s1) { const float4 r = pos[jn1]; qn = (v4f){r.x, r.y, r.z, r.w}; }
+        const v4f *__restrict__ cur = tile[it & 1] + w * JW;
+#pragma unroll UNROLL
+        for (int jj = 0; jj < (int)JW; ++jj) {
+            const v4f q = cur[jj];
+            const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, zj = {q.z, q.z}, mj = {q.w, q.w};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const v2f dx = xj - xi[p], dy = yj - yi[p], dz = zj - zi[p];
+                v2f r2, inv;
+                if constexpr (GUARD) {
+                    r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else inv = quake_rsqrt2(r2);
+                    inv.x = r2.x > 0.f ? inv.x : 0.f;
+                    inv.y = r2.y > 0.f ? inv.y : 0.f;
+                } else {
+                    r2 = __builtin_elementwise_fma(dx, dx, e2);
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    r2 = __builtin_elementwise_fma(dz, dz, r2);
+                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else inv = quake_rsqrt2(r2);
+                }
+                const v2f inv2 = inv * inv;
+                v2f s;
+                if constexpr (UM) s = inv * inv2; else s = (mj * inv) * inv2;
+                ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
+                ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
+                az[p] = __builtin_elementwise_fma(s, dz, az[p]);
+            }
+        }
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = qn;
+        __syncthreads();
+    }
+    // combine the WS wave groups in order through LDS
+    if (w > 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            smem[(((w - 1) * P + p) * LANES_I + lane_i) * 2 + 0] = (v4f){ax[p].x, ay[p].x, az[p].x, 0.f};
+            smem[(((w - 1) * P + p) * LANES_I + lane_i) * 2 + 1] = (v4f){ax[p].y, ay[p].y, az[p].y, 0.f};
+        }
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float4 *__restrict__ out = partial + (size_t)tm.slice * i_count;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int k = 0; k < WS - 1; ++k) {
+            const v4f r0 = smem[((k * P + p) * LANES_I + lane_i) * 2 + 0], r1 = smem[((k * P + p) * LANES_I + lane_i) * 2 + 1];
+            ax[p] += (v2f){r0.x, r1.x}; ay[p] += (v2f){r0.y, r1.y}; az[p] += (v2f){r0.z, r1.z};
+        }
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; az[p] *= um_mass; }
+        if (li[p] < i_count) out[li[p]] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.f);
+        if (li[p] + 1 < i_count) out[li[p] + 1] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force_sym3_f32 — symmetric fast path in 3-D.  Same items / tiles / slab scheme as force_sym_f32
+// (DESIGN.md §4.1): 8 stationary particles per lane as 4 packed pairs, one travelling particle per
+// lane rotated with ds_bpermute_b32 (x, y, z [, m] and six accumulator halves: 9-10 per step).
+// Body, both directions: 3 pk_add + 3 pk_fma + 2 rsq + 2 pk_mul + 6 pk_fma = 14 packed + 2 trans.
+// ---------------------------------------------------------------------------
+template <int RSQ, bool UM, bool DIAG>
+__device__ __forceinline__
+void sym3_chunks(const float4 *__restrict__ pos, float4 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                 const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&zi)[SYM_P], const v2f (&mi)[SYM_P],
+                 v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], v2f (&az)[SYM_P], float eps2, float um_mass, float4 (*red)[4][64])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    const v2f e2 = {eps2, eps2};
+    float xq = PAD_XY, yq = PAD_XY, zq = PAD_XY, mq = 0.f;
+    {
+        const uint32_t j = c0 * SYM_CH + lane;
+        if (j < n) { const float4 pj = pos[j]; xq = pj.x; yq = pj.y; zq = pj.z; mq = pj.w; }
+    }
+    for (uint32_t c = 0; c < cnt; ++c) {
+        float xn = PAD_XY, yn = PAD_XY, zn = PAD_XY, mn = 0.f;
+        {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (c + 1 < cnt && j < n) { const float4 pj = pos[j]; xn = pj.x; yn = pj.y; zn = pj.z; mn = pj.w; }
+        }
+        v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f}, aqz = {0.f, 0.f};
+#pragma unroll SYM_UNROLL
+        for (int step = 0; step < 64; ++step) {
+            const float xr = lane_rot(xq, addr), yr = lane_rot(yq, addr), zr = lane_rot(zq, addr);
+            float mr = 0.f;
+            if constexpr (!UM) mr = lane_rot(mq, addr);
+            const v2f xj = {xq, xq}, yj = {yq, yq}, zj = {zq, zq};
+#pragma unroll
+            for (int p = 0; p < SYM_P; ++p) {
+                const v2f dx = xj - xi[p], dy = yj - yi[p], dz = zj - zi[p];
+                v2f r2 = __builtin_elementwise_fma(dx, dx, e2);
+                r2 = __builtin_elementwise_fma(dy, dy, r2);
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+                v2f inv;
+                if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                else inv = quake_rsqrt2(r2);
+                const v2f inv3 = inv * (inv * inv);
+                v2f si = inv3, sj = inv3;
+                if constexpr (!UM) { si = (v2f){mq, mq} * inv3; sj = mi[p] * inv3; }
+                ax[p] = __builtin_elementwise_fma(si, dx, ax[p]);
+                ay[p] = __builtin_elementwise_fma(si, dy, ay[p]);
+                az[p] = __builtin_elementwise_fma(si, dz, az[p]);
+                if constexpr (!DIAG) {
+                    aqx = __builtin_elementwise_fma(-sj, dx, aqx);
+                    aqy = __builtin_elementwise_fma(-sj, dy, aqy);
+                    aqz = __builtin_elementwise_fma(-sj, dz, aqz);
+                }
+            }
+            xq = xr; yq = yr; zq = zr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) {
+                aqx.x = lane_rot(aqx.x, addr); aqx.y = lane_rot(aqx.y, addr);
+                aqy.x = lane_rot(aqy.x, addr); aqy.y = lane_rot(aqy.y, addr);
+                aqz.x = lane_rot(aqz.x, addr); aqz.y = lane_rot(aqz.y, addr);
+            }
+        }
+        if constexpr (!DIAG) {
+            float4 r = make_float4(aqx.x + aqx.y, aqy.x + aqy.y, aqz.x + aqz.y, 0.f);
+            if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; r.z *= um_mass; }
+            float4 (*rb)[64] = red[c & 1u];
+            rb[w][lane] = r;
+            __syncthreads();
+            if (w == 0) {
+                const uint32_t j = (c0 + c) * SYM_CH + lane;
+                float4 a = rb[0][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; a.z += rb[k][lane].z; }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn; zq = zn;
+        if constexpr (!UM) mq = mn;
+    }
+}
+
+template <int RSQ, bool UM>
+__global__ __launch_bounds__(BLOCK)
+void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ items,
+                    float4 *__restrict__ slab_s, float4 *__restrict__ slab_r, uint32_t n, float eps2, float um_mass)
+{
+    __shared__ float4 red[2][4][64];
+    const SymItem it = items[blockIdx.x];
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    v2f xi[SYM_P], yi[SYM_P], zi[SYM_P], mi[SYM_P], ax[SYM_P], ay[SYM_P], az[SYM_P];
+    uint32_t li[SYM_P];
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        li[p] = w * SYM_WT + (uint32_t)p * 128u + 2u * lane;
+        const uint32_t g0 = it.tile * SYM_SB + li[p], g1 = g0 + 1;
+        float4 p0 = make_float4(PAD_XY, PAD_XY, PAD_XY, 0.f), p1 = p0;
+        if (g0 < n) p0 = pos[g0];
+        if (g1 < n) p1 = pos[g1];
+        xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; zi[p] = (v2f){p0.z, p1.z}; mi[p] = (v2f){p0.w, p1.w};
+        ax[p] = ay[p] = az[p] = (v2f){0.f, 0.f};
+    }
+    float4 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
+    if (it.diag) sym3_chunks<RSQ, UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    else         sym3_chunks<RSQ, UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    float4 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; az[p] *= um_mass; }
+        out[li[p]] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.f);
+        out[li[p] + 1] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.f);
+    }
+}
+
+// sum of the stationary rows of particle k's tile + the travelling rows of earlier tiles, then kick/drift
+template <bool FUSE>
+__global__ __launch_bounds__(BLOCK)
+void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ slab_r,
+                 const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row, uint32_t n,
+                 float4 *__restrict__ acc_sum, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
+                 float4 *__restrict__ vel, float4 *__restrict__ acc, float dt_kick, float dt_drift, int flags)
+{
+    __shared__ float4 part[GATHER_Q][GATHER_P];
+    const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
+    const uint32_t k = blockIdx.x * GATHER_P + p;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < n) {
+        const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
+        for (uint32_t r = rowbase[g] + q; r < rowbase[g + 1]; r += GATHER_Q) {
+            const float4 b = slab_s[(size_t)r * SYM_SB + loc];
+            a.x += b.x; a.y += b.y; a.z += b.z;
+        }
+        for (uint32_t i = q; i < g; i += GATHER_Q) {
+            const uint32_t rr = tile_row[i];
+            if (rr == SYM_NONE) continue;
+            const float4 b = slab_r[(size_t)rr * n + k];
+            a.x += b.x; a.y += b.y; a.z += b.z;
+        }
+    }
+    part[q][p] = a;
+    __syncthreads();
+    if (q == 0 && k < n) {
+        float4 s = part[0][p];
+#pragma unroll
+        for (int j = 1; j < GATHER_Q; ++j) { s.x += part[j][p].x; s.y += part[j][p].y; s.z += part[j][p].z; }
+        if constexpr (FUSE) kick_drift_one3(s, k, pos_cur, pos_next, vel, acc, 0u, dt_kick, dt_drift, flags);
+        else acc_sum[k] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// AoS (64-byte records, z in the first padding slot of pos / vel / acc) <-> SoA float4
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK)
+void unpack_bodies3(const BodyRec *__restrict__ aos, uint32_t n, float4 *__restrict__ pos, float4 *__restrict__ vel,
+                    float4 *__restrict__ acc, float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = aos[i].q[0], m = aos[i].q[3];
+    pos[i] = make_float4(p.x, p.y, p.z, m.x);
+    radius[i] = m.y;
+    if (i >= i_begin && i - i_begin < i_count) {
+        const float4 v = aos[i].q[1], a = aos[i].q[2];
+        vel[i - i_begin] = make_float4(v.x, v.y, v.z, 0.f);
+        acc[i - i_begin] = make_float4(a.x, a.y, a.z, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK)
+void pack_bodies3(BodyRec *__restrict__ aos, const float4 *__restrict__ pos, const float4 *__restrict__ vel,
+                  const float4 *__restrict__ acc, const float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    const float4 p = pos[i_begin + li], v = vel[li], a = acc[li];
+    BodyRec r;
+    r.q[0] = make_float4(p.x, p.y, p.z, 0.f);
+    r.q[1] = make_float4(v.x, v.y, v.z, 0.f);
+    r.q[2] = make_float4(a.x, a.y, a.z, 0.f);
+    r.q[3] = make_float4(p.w, radius[i_begin + li], 0.f, 0.f);
+    aos[li] = r;
+}
+
+// energy in fp64: K = sum m v^2 / 2, U = -1/2 sum_i m_i sum_{j != i} m_j / sqrt(r^2 + eps^2)
+__global__ __launch_bounds__(BLOCK)
+void energy_partials3(const float4 *__restrict__ pos, const float4 *__restrict__ vel, uint32_t n,
+                      uint32_t i_begin, uint32_t i_count, double eps2, double *__restrict__ ksum, double *__restrict__ usum)
+{
+    struct alignas(16) JD { double x, y, z, m; };
+    __shared__ JD tile[TJ];
+    __shared__ double red[2][BLOCK / 64];
+    const uint32_t t = threadIdx.x, li = blockIdx.x * BLOCK + t;
+    const bool live = li < i_count;
+    const uint32_t gi = i_begin + (live ? li : i_count - 1);
+    const float4 pi = pos[gi];
+    const double xi = pi.x, yi = pi.y, zi = pi.z;
+    double u = 0.0;
+    for (uint32_t j0 = 0; j0 < n; j0 += TJ) {
+        const uint32_t j = j0 + t;
+        __syncthreads();
+        if (j < n) { const float4 q = pos[j]; tile[t] = JD{(double)q.x, (double)q.y, (double)q.z, (double)q.w}; }
+        else tile[t] = JD{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)TJ, n - j0);
+        for (uint32_t jj = 0; jj < cnt; ++jj) {
+            const double dx = tile[jj].x - xi, dy = tile[jj].y - yi, dz = tile[jj].z - zi;
+            const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+            const double wgt = (j0 + jj == gi) ? 0.0 : tile[jj].m;
+            u += wgt / sqrt(r2);
+        }
+    }
+    double k = 0.0, uu = 0.0;
+    if (live) {
+        const double m = (double)pi.w;
+        const float4 v = vel[li];
+        k = 0.5 * m * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
+        uu = -0.5 * m * u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { k += __shfl_down(k, off, 64); uu += __shfl_down(uu, off, 64); }
+    if ((t & 63) == 0) { red[0][t >> 6] = k; red[1][t >> 6] = uu; }
+    __syncthreads();
+    if (t == 0) {
+        double ks = 0.0, us = 0.0;
+        for (int wv = 0; wv < BLOCK / 64; ++wv) { ks += red[0][wv]; us += red[1][wv]; }
+        ksum[blockIdx.x] = ks;
+        usum[blockIdx.x] = us;
+    }
+}
+
+} // namespace nbk

@@ -50,11 +50,14 @@ class Simulation:
         shard_rank: int = 0,
         shard_world: int = 0,
         acc_buffers: Optional[tuple] = None,
+        dims: int = 2,
     ):
         lib = L.load()
-        if bodies.dtype != L.BODY_DTYPE:
+        if bodies.dtype not in (L.BODY_DTYPE, L.BODY3_DTYPE):
             raise TypeError("bodies must be a numpy array of nbodysim_amd.BODY_DTYPE (64-byte Body records)")
         bodies = np.ascontiguousarray(bodies)
+        view = L.BODY3_DTYPE if dims == 3 else L.BODY_DTYPE
+        bodies = bodies.view(view)
         p = L.default_params()
         p.eps = eps
         p.dt = SIMULATION_DT
@@ -71,6 +74,7 @@ class Simulation:
             p.stream = stream
         if pos_buffers is not None:
             p.pos_buffers[0], p.pos_buffers[1] = pos_buffers
+        p.dims = dims
         p.shard_rank, p.shard_world = shard_rank, shard_world
         if acc_buffers is not None:
             p.acc_buffers[0], p.acc_buffers[1] = acc_buffers
@@ -83,7 +87,7 @@ class Simulation:
         self.i_begin = int(lib.nb_owned_begin(self._h))
         self.i_count = int(lib.nb_owned_count(self._h))
         #: host view of the owned block; refreshed by step() / sync()
-        self.bodies = bodies[self.i_begin : self.i_begin + self.i_count].copy()
+        self.bodies = np.frombuffer(bodies[self.i_begin : self.i_begin + self.i_count].tobytes(), dtype=view).copy()
 
     # -- reference surface ---------------------------------------------------
     @property

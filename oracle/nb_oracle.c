@@ -229,3 +229,56 @@ void nbo_energy_f64(size_t n, const double *x, const double *y,
     *kinetic = K;
     *potential = U;
 }
+
+/* ---- 3-D extension: same arithmetic with a z term, fp64 (no reference to pin to) ---- */
+void nbo_accel3_f64(size_t n, const double *x, const double *y, const double *z, const double *m,
+                    double eps2, double *ax, double *ay, double *az)
+{
+    const int nt = nbo_get_threads();
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i) {
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            const double rx = x[j] - x[i], ry = y[j] - y[i], rz = z[j] - z[i];
+            const double r_sq = rx * rx + ry * ry + rz * rz;
+            if (r_sq > 0) {
+                const double inv = 1.0 / sqrt(r_sq + eps2);
+                const double s = m[j] * (inv * inv * inv);
+                sx += rx * s; sy += ry * s; sz += rz * s;
+            }
+        }
+        ax[i] = sx; ay[i] = sy; az[i] = sz;
+    }
+}
+
+void nbo_step3_f64(size_t n, double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                   const double *m, double *ax, double *ay, double *az, double eps2, double dt, int nsteps)
+{
+    for (int s = 0; s < nsteps; ++s) {
+        nbo_accel3_f64(n, x, y, z, m, eps2, ax, ay, az);
+        for (size_t i = 0; i < n; ++i) { vx[i] += ax[i] * dt; vy[i] += ay[i] * dt; vz[i] += az[i] * dt; }
+        for (size_t i = 0; i < n; ++i) { x[i] += vx[i] * dt; y[i] += vy[i] * dt; z[i] += vz[i] * dt; }
+    }
+}
+
+void nbo_energy3_f64(size_t n, const double *x, const double *y, const double *z,
+                     const double *vx, const double *vy, const double *vz, const double *m,
+                     double eps2, double *kinetic, double *potential)
+{
+    double K = 0.0, U = 0.0;
+    for (size_t i = 0; i < n; ++i) K += 0.5 * m[i] * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+    const int nt = nbo_get_threads();
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : U) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i) {
+        double u = 0.0;
+        for (size_t j = (size_t)i + 1; j < n; ++j) {
+            const double rx = x[j] - x[i], ry = y[j] - y[i], rz = z[j] - z[i];
+            u += m[j] / sqrt(rx * rx + ry * ry + rz * rz + eps2);
+        }
+        U -= m[i] * u;
+    }
+    *kinetic = K;
+    *potential = U;
+}

@@ -63,6 +63,18 @@ void nbo_energy_f64(size_t n, const double *x, const double *y,
                     const double *vx, const double *vy, const double *m,
                     double eps2, double *kinetic, double *potential);
 
+/* ---- 3-D build extension ----------------------------------------
+ * The reference is 2-D only; these restate the SAME softened pair force with a z term
+ * (20 flop per pair) in fp64.  There is no reference output to pin them to: the 3-D
+ * parity claims are "against the fp64 restatement" only (parity unpinned). */
+void nbo_accel3_f64(size_t n, const double *x, const double *y, const double *z, const double *m,
+                    double eps2, double *ax, double *ay, double *az);
+void nbo_step3_f64(size_t n, double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                   const double *m, double *ax, double *ay, double *az, double eps2, double dt, int nsteps);
+void nbo_energy3_f64(size_t n, const double *x, const double *y, const double *z,
+                     const double *vx, const double *vy, const double *vz, const double *m,
+                     double eps2, double *kinetic, double *potential);
+
 #ifdef __cplusplus
 }
 #endif

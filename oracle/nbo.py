@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
         l.nbo_step_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
         l.nbo_kick_drift_f32.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int]
         l.nbo_energy_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        l.nbo_accel3_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p]
+        l.nbo_step3_f64.argtypes = [C.c_size_t] + [_f64p] * 10 + [C.c_double, C.c_double, C.c_int]
+        l.nbo_energy3_f64.argtypes = [C.c_size_t] + [_f64p] * 7 + [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         l.nbo_set_threads(int(os.environ.get("NBO_THREADS", host_threads())))
         _lib = l
     return _lib
@@ -175,6 +178,38 @@ def energy(st: dict, eps: float):
     d = {k: np.ascontiguousarray(st[k], dtype=np.float64) for k in ("x", "y", "vx", "vy", "m")}
     k, u = C.c_double(), C.c_double()
     lib().nbo_energy_f64(d["x"].shape[0], d["x"], d["y"], d["vx"], d["vy"], d["m"], float(eps) ** 2, C.byref(k), C.byref(u))
+    return k.value, u.value
+
+
+# ---- 3-D extension (fp64 only; no reference to pin to) ---------------------------
+def state3_from_bodies(bodies3: np.ndarray) -> dict:
+    """bodies3: structured array viewed with 3-component pos / vel / acc (nbodysim_amd.BODY3_DTYPE)."""
+    d = {}
+    for k, f, c in (("x", "pos", 0), ("y", "pos", 1), ("z", "pos", 2), ("vx", "vel", 0), ("vy", "vel", 1), ("vz", "vel", 2)):
+        d[k] = np.ascontiguousarray(bodies3[f][:, c], dtype=np.float64)
+    d["m"] = np.ascontiguousarray(bodies3["mass"], dtype=np.float64)
+    for k in ("ax", "ay", "az"):
+        d[k] = np.zeros_like(d["x"])
+    return d
+
+
+def accel3_f64(st: dict, eps: float):
+    n = st["x"].shape[0]
+    lib().nbo_accel3_f64(n, st["x"], st["y"], st["z"], st["m"], float(eps) ** 2, st["ax"], st["ay"], st["az"])
+    return st["ax"], st["ay"], st["az"]
+
+
+def step3_f64(st: dict, eps: float, dt: float, nsteps: int) -> dict:
+    n = st["x"].shape[0]
+    lib().nbo_step3_f64(n, st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], st["ax"], st["ay"], st["az"],
+                        float(eps) ** 2, dt, nsteps)
+    return st
+
+
+def energy3(st: dict, eps: float):
+    k, u = C.c_double(), C.c_double()
+    lib().nbo_energy3_f64(st["x"].shape[0], st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], float(eps) ** 2,
+                          C.byref(k), C.byref(u))
     return k.value, u.value
 
 

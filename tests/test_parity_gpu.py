@@ -292,29 +292,20 @@ def test_fp64_energy_drift_small(nbo):
 
 # --------------------------------------------------------------- sharding ---
 def _run_sharded(ic, parts, steps, dt, **kw):
-    """Drive P handles on one GPU through begin / exchange / finish; the exchange
-    is a device-side copy of each owner's block into every other replica."""
+    """Drive P handles on one GPU through begin / finish / exchange in ONE process; the exchange is the
+    library's own in-process all-gather (nb_exchange_positions)."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    lib = nb.load()
     n = ic.shape[0]
     bounds = np.linspace(0, n, parts + 1).astype(int)
     sims = [nb.Simulation(ic, i_begin=int(bounds[r]), i_count=int(bounds[r + 1] - bounds[r]), **kw) for r in range(parts)]
-    rsz = 16 if kw.get("precision") == "fp64" else 8
+    handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
     for _ in range(steps):
         for s in sims:
             s.step_begin(dt)
         for s in sims:
             s.step_finish()
-        for s in sims:
-            s.wait()
-        for owner in sims:   # all-gather by hand
-            src = owner.pos_buffer(L.NB_POS_CURRENT) + owner.i_begin * rsz
-            for other in sims:
-                if other is owner:
-                    continue
-                dst = other.pos_buffer(L.NB_POS_CURRENT) + owner.i_begin * rsz
-                rc = hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(owner.i_count * rsz), 3)
-                assert rc == 0
+        L.check("nb_exchange_positions", lib.nb_exchange_positions(handles, parts))
     out = nb.bodies_array(n)
     for s in sims:
         out[s.i_begin : s.i_begin + s.i_count] = s.sync()
