@@ -82,6 +82,7 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=N_DEFAULT)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--rsqrt", default="exact", choices=["exact", "quake"])
+    ap.add_argument("--dims", type=int, default=2, choices=[2, 3], help="3 = the 3-D build extension (not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -107,7 +108,8 @@ def main() -> None:
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
-    ic = nb.plummer_2d(n, SEED)   # every rank generates the same deterministic ICs
+    ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)   # every rank generates the same deterministic ICs
+    flop_per_pair = FLOP_PER_PAIR if args.dims == 2 else 20.0   # 3-D: one more sub, fma, fma per pair side
 
     if world > 1:
         import torch.distributed as dist
@@ -125,7 +127,7 @@ def main() -> None:
         def barrier():
             dist.barrier()
     else:
-        sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank)
+        sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims)
         inner = sim
         advance, wait = sim.advance, sim.wait
 
@@ -163,10 +165,10 @@ def main() -> None:
         pairs_this_rank = float(inner.i_count) * float(n) * args.steps
         if launches and force_ms > 0:
             kern_s = force_ms * 1e-3
-            achieved = FLOP_PER_PAIR * pairs_this_rank / kern_s / 1e12
+            achieved = flop_per_pair * pairs_this_rank / kern_s / 1e12
             avg_launch_ms = force_ms / launches
         else:
-            achieved = FLOP_PER_PAIR * pairs_this_rank / elapsed / 1e12
+            achieved = flop_per_pair * pairs_this_rank / elapsed / 1e12
             avg_launch_ms = None
         traffic = None
         tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived, written by tools/collect_profile.sh
@@ -195,7 +197,7 @@ def main() -> None:
                             f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, "
                             + ("symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step"
                                if getattr(sim, "symmetric", False) else "all-gather of (x,y) per step overlapped with the local-tile force"),
-                "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled",
+                "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled", "dims": args.dims,
                 "parallelism": f"i-block x{world}" if world > 1 else "single GPU",
                 "backend": args.backend if world > 1 else None,
                 "launch": inner.describe(),
@@ -207,7 +209,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2),
                 "traffic": traffic,
-                "flop_per_pair": FLOP_PER_PAIR,
+                "flop_per_pair": flop_per_pair,
                 "kernel": ("force_sym_" if "symmetric=1" in inner.describe() else "force_tiled_") + ("f32" if args.precision == "fp32" else "f64"),
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
@@ -220,7 +222,7 @@ def main() -> None:
             "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                        "steps": args.warmup + args.steps},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dims == 2:
             line["cpu_baseline"] = cpu_baseline(ic, n)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
