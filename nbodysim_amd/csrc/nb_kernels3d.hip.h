@@ -374,7 +374,7 @@ void energy_partials3(const float4 *__restrict__ pos, const float4 *__restrict__
             const double dx = tile[jj].x - xi, dy = tile[jj].y - yi, dz = tile[jj].z - zi;
             const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
             const double wgt = (j0 + jj == gi) ? 0.0 : tile[jj].m;
-            u += wgt / sqrt(r2);
+            u = __builtin_fma(wgt, rsqrt_f64(r2), u);
         }
     }
     double k = 0.0, uu = 0.0;

@@ -90,3 +90,20 @@ def test_3d_rejects_unsupported_combinations():
     for kw in (dict(precision="fp64"), dict(order="sequential"), dict(extras=1), dict(i_begin=0, i_count=500)):
         with pytest.raises(nb.NBodyError):
             nb.Simulation(ic, dims=3, **kw)
+
+
+def test_3d_kdk_integrator_matches_numpy_leapfrog(nbo):
+    ic = nb.plummer_3d(3000, 6).view(nb.BODY3_DTYPE)
+    eps, dt, steps = f32(0.05), f32(2e-3), 4
+    with nb.Simulation(ic, eps=eps, dims=3, integrator="kdk") as sim:
+        sim.advance(steps, dt)
+        got = sim.sync()
+    st = nbo.state3_from_bodies(ic)
+    ax, ay, az = (a.copy() for a in nbo.accel3_f64(st, eps))
+    for _ in range(steps):
+        st["vx"] += 0.5 * dt * ax; st["vy"] += 0.5 * dt * ay; st["vz"] += 0.5 * dt * az
+        st["x"] += dt * st["vx"]; st["y"] += dt * st["vy"]; st["z"] += dt * st["vz"]
+        ax, ay, az = (a.copy() for a in nbo.accel3_f64(st, eps))
+        st["vx"] += 0.5 * dt * ax; st["vy"] += 0.5 * dt * ay; st["vz"] += 0.5 * dt * az
+    assert max_rel(got["pos"], np.stack([st["x"], st["y"], st["z"]], 1)) < 1e-5
+    assert max_rel(got["vel"], np.stack([st["vx"], st["vy"], st["vz"]], 1)) < 1e-5

@@ -158,3 +158,28 @@ def test_product_does_not_reference_oracle():
             assert "nb_oracle" not in txt and "import nbo" not in txt and "libnbref" not in txt, p
     out = subprocess.run(["ldd", str(L.LIB_PATH)], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_plummer_3d_is_the_unprojected_2d_sample():
+    """nb_plummer_3d keeps z; its (x, y) and (vx, vy) are exactly nb_plummer_2d's."""
+    b2 = nb.plummer_2d(5000, 8)
+    b3 = nb.plummer_3d(5000, 8).view(nb.BODY3_DTYPE)
+    assert np.array_equal(b3["pos"][:, :2], b2["pos"]) and np.array_equal(b3["vel"][:, :2], b2["vel"])
+    r = np.linalg.norm(b3["pos"].astype(np.float64), axis=1)
+    assert abs(np.median(r) - 1.3048) < 0.03          # Plummer half-mass radius (a = 1): 1.3048
+    assert r.max() <= 20.0 + 1e-4 and b3["pos"][:, 2].std() > 0.5
+    v2 = (b3["vel"].astype(np.float64) ** 2).sum(1).mean()
+    assert abs(v2 - 3.0 * np.pi / 32.0) < 0.01        # <v^2> = 3 pi / 32
+
+
+def test_dump_header_records_dims(tmp_path):
+    import ctypes as C
+    b3 = nb.plummer_3d(100, 1)
+    p = L.default_params(); p.dims = 3
+    assert nb.load().nb_write_bodies(str(tmp_path / "d3").encode(), b3.ctypes.data, 100, 5, C.byref(p)) == 0
+    back, frame, q = nb.read_bodies(tmp_path / "d3")
+    assert q.dims == 3 and frame == 5 and back.tobytes() == b3.tobytes()
+    p.dims = 2
+    assert nb.load().nb_write_bodies(str(tmp_path / "d2").encode(), b3.ctypes.data, 100, 5, C.byref(p)) == 0
+    back2, _, q2 = nb.read_bodies(tmp_path / "d2")
+    assert q2.dims == 2 and not back2.view(nb.BODY3_DTYPE)["pos"][:, 2].any()    # planar dumps zero the padding
