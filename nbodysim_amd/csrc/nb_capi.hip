@@ -255,7 +255,9 @@ static int plan_sym(nb_sim *s)
         if (first < chunks) total += chunks - first;
     }
     const char *envl = getenv("NB_SYM_L");
-    const uint32_t target = 32u * (uint32_t)s->cus;
+    // ~32 workgroups per CU on a single GPU, ~16 on a sharded rank, whose items are shorter
+    // (profiles/r01_shard_sym_per_rank_sweep.log: L = 8 beats L = 4 at an 8-way split)
+    const uint32_t target = (world > 1 ? 16u : 32u) * (uint32_t)s->cus;
     uint32_t L = envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : (uint32_t)((total + target - 1) / target);
     if (L < 1) L = 1;
     std::vector<SymItem> items;

@@ -7,6 +7,8 @@
  *
  *   nbody_main [-n N] [-s steps] [-dt DT] [-eps EPS] [-seed S] [-fp64] [-quake]
  *              [-sequential] [-kdk] [-dump FILE] [-load FILE] [-sync-every K]
+ *              [-shards P]   P sharded handles driven from this one process (device r mod #GPUs),
+ *                            exchanged with nb_exchange_positions: multi-GPU without RCCL
  */
 #include "nbody.h"
 
@@ -28,7 +30,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
     size_t n = 65536;
-    int steps = 20, sync_every = 0;
+    int steps = 20, sync_every = 0, shards = 1;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
     nb_params p;
@@ -48,6 +50,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "-load") && i + 1 < argc) load = argv[++i];
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-shards") && i + 1 < argc) shards = atoi(argv[++i]);
         else DIE("unknown argument %s", argv[i]);
     }
 
@@ -66,6 +69,34 @@ int main(int argc, char **argv)
         CHECK(nb_plummer_2d(bodies, n, seed));
     }
 
+    if (shards > 1) {
+        /* one process, `shards` handles: each integrates a contiguous block */
+        if (shards > 64 || n % (size_t)shards) DIE("-shards must divide n (and be <= 64)");
+        nb_sim *h[64];
+        const int ndev = nb_device_count();
+        const size_t blk = n / (size_t)shards;
+        for (int r = 0; r < shards; ++r) {
+            nb_params q = p;
+            q.i_begin = (uint64_t)r * blk; q.i_count = blk; q.device = ndev > 0 ? r % ndev : 0;
+            h[r] = nb_create(bodies, n, &q);
+            if (!h[r]) DIE("nb_create(shard %d): %s", r, nb_last_error());
+        }
+        const double t0s = now_s();
+        for (int s = 0; s < steps; ++s) {
+            for (int r = 0; r < shards; ++r) CHECK(nb_step_begin(h[r], p.dt));
+            for (int r = 0; r < shards; ++r) CHECK(nb_step_finish(h[r]));
+            CHECK(nb_exchange_positions(h, shards));
+        }
+        const double pers = (now_s() - t0s) / steps;
+        for (int r = 0; r < shards; ++r) CHECK(nb_sync(h[r], bodies + (size_t)r * blk));
+        printf("shards=%d on %d device(s): frame=%llu  %.3f ms/step  %.3e pair interactions/s\n", shards, ndev,
+               (unsigned long long)nb_frame(h[0]), pers * 1e3, (double)n * (double)n / pers);
+        printf("body[0]: pos=(%.6f, %.6f) vel=(%.6f, %.6f)\n", bodies[0].pos.x, bodies[0].pos.y, bodies[0].vel.x, bodies[0].vel.y);
+        if (dump) { CHECK(nb_write_bodies(dump, bodies, n, nb_frame(h[0]), &p)); printf("dumped to %s\n", dump); }
+        for (int r = 0; r < shards; ++r) nb_destroy(h[r]);
+        free(bodies);
+        return 0;
+    }
     nb_sim *sim = nb_create(bodies, n, &p);
     if (!sim) DIE("nb_create: %s", nb_last_error());
     const int pinned = nb_host_register(bodies, n * sizeof *bodies) == NB_OK;   /* nb_sync then DMAs into `bodies` */
