@@ -260,6 +260,13 @@ int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed);
 /* The same sample without the projection: a true 3-D Plummer sphere (z in NB_Z) for dims = 3. */
 int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
 
+/* Host-only view of the symmetric kernel's work planner (no GPU needed; used by the CPU tests to check
+ * that the items of all ranks cover every unordered (tile, chunk) pair exactly once and are balanced).
+ * items_out receives up to cap items of 8 uint32: tile, first chunk, chunk count, stationary slab row,
+ * travelling slab row, diagonal flag, 0, 0.  Tiles are 2048 particles, chunks 64. */
+int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
+                      uint32_t *n_items, uint32_t *chunks_per_item);
+
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);
 

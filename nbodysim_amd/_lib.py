@@ -117,6 +117,7 @@ PROTOTYPES = {
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),

@@ -241,11 +241,12 @@ static uint32_t tile_owner(uint32_t I, uint32_t world)
     return (round & 1u) ? world - 1 - k : k;
 }
 
-static int plan_sym(nb_sim *s)
+// Pure planner of the symmetric scheme (no device calls; also behind nb_debug_sym_plan for the CPU tests):
+// the work items of `rank`, the first slab_s row of every tile (rowbase, tiles + 1 entries) and the slab_r
+// row of every tile (SYM_NONE for tiles dealt to other ranks).  Returns chunks per item.
+static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, uint32_t forced_L,
+                               std::vector<SymItem> &items, std::vector<uint32_t> &rowbase, std::vector<uint32_t> &tile_row)
 {
-    const uint32_t n = (uint32_t)s->n;
-    const uint32_t world = s->sym_sharded ? (uint32_t)s->p.shard_world : 1u;
-    const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
     // chunks strictly after tile I: chunks - (I+1)*cpt (>= 0); only this rank's tiles count
     uint64_t total = 0;
@@ -254,14 +255,14 @@ static int plan_sym(nb_sim *s)
         const uint32_t first = (I + 1) * cpt;
         if (first < chunks) total += chunks - first;
     }
-    const char *envl = getenv("NB_SYM_L");
     // ~32 workgroups per CU on a single GPU, ~16 on a sharded rank, whose items are shorter
     // (profiles/r01_shard_sym_per_rank_sweep.log: L = 8 beats L = 4 at an 8-way split)
-    const uint32_t target = (world > 1 ? 16u : 32u) * (uint32_t)s->cus;
-    uint32_t L = envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : (uint32_t)((total + target - 1) / target);
+    const uint32_t target = (world > 1 ? 16u : 32u) * cus;
+    uint32_t L = forced_L ? forced_L : (uint32_t)((total + target - 1) / target);
     if (L < 1) L = 1;
-    std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase(tiles + 1, 0), tile_row(tiles, SYM_NONE);
+    items.clear();
+    rowbase.assign(tiles + 1, 0);
+    tile_row.assign(tiles, SYM_NONE);
     uint32_t row = 0, rrow = 0;
     for (uint32_t I = 0; I < tiles; ++I) {
         rowbase[I] = row;
@@ -281,6 +282,36 @@ static int plan_sym(nb_sim *s)
         ++rrow;
     }
     rowbase[tiles] = row;
+    return L;
+}
+
+// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag, 0, 0).
+extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
+                                 uint32_t *n_items, uint32_t *chunks_per_item)
+{
+    if (n == 0 || n > 0x7fffff00u || cus < 1 || world < 1 || rank < 0 || rank >= world) { nb_set_error("nb_debug_sym_plan: bad arguments"); return NB_EINVAL; }
+    std::vector<SymItem> items;
+    std::vector<uint32_t> rowbase, tile_row;
+    const uint32_t L = build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, items, rowbase, tile_row);
+    if (n_items) *n_items = (uint32_t)items.size();
+    if (chunks_per_item) *chunks_per_item = L;
+    if (items_out) memcpy(items_out, items.data(), (items.size() < cap ? items.size() : cap) * sizeof(SymItem));
+    return NB_OK;
+}
+
+static int plan_sym(nb_sim *s)
+{
+    const uint32_t n = (uint32_t)s->n;
+    const uint32_t world = s->sym_sharded ? (uint32_t)s->p.shard_world : 1u;
+    const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
+    const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB;
+    const char *envl = getenv("NB_SYM_L");
+    std::vector<SymItem> items;
+    std::vector<uint32_t> rowbase, tile_row;
+    const uint32_t L = build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u, items, rowbase, tile_row);
+    const uint32_t row = rowbase[tiles];
+    uint32_t rrow = 0;
+    for (uint32_t r : tile_row) if (r != SYM_NONE) ++rrow;
     s->sym_items = (uint32_t)items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = L;
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));

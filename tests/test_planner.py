@@ -1,0 +1,67 @@
+"""CPU: the symmetric kernel's host-side work planner (nb_debug_sym_plan).  The 8-GPU partition cannot be
+run in this container, so its correctness is checked by construction: over all ranks, every unordered pair
+of (2048-particle tile, 64-particle chunk) is covered exactly once — diagonal items cover a tile's own
+chunks, symmetric items the chunks after it — slab rows are unique, and the ranks' work is balanced."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nbodysim_amd as nb
+
+SB, CH = 2048, 64
+
+
+def plan(n, rank, world, cus=256):
+    lib = nb.load()
+    cnt, L = C.c_uint32(), C.c_uint32()
+    assert lib.nb_debug_sym_plan(n, cus, rank, world, None, 0, C.byref(cnt), C.byref(L)) == 0
+    items = np.zeros((cnt.value, 8), np.uint32)
+    assert lib.nb_debug_sym_plan(n, cus, rank, world, items.ctypes.data, cnt.value, C.byref(cnt), C.byref(L)) == 0
+    return items, int(L.value)
+
+
+@pytest.mark.parametrize("n,world", [(16384, 1), (20000, 1), (70001, 1), (262144, 1), (262144, 2), (262144, 4), (262144, 8),
+                                     (65536, 8), (1048576, 8), (100000, 3)])
+def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
+    tiles, chunks, cpt = -(-n // SB), -(-n // CH), SB // CH
+    cover = np.zeros((tiles, chunks), np.int32)
+    work = []
+    for rank in range(world):
+        items, L = plan(n, rank, world)
+        assert len(items) > 0 and L >= 1
+        # slab rows: stationary rows unique and dense per rank, travelling row constant per tile
+        assert sorted(items[:, 3]) == list(range(len(items)))
+        w = 0
+        rrow_of = {}
+        for tile, c0, cnt, s_row, r_row, diag, _, _ in items:
+            assert 1 <= cnt <= L and c0 + cnt <= chunks
+            assert rrow_of.setdefault(int(tile), int(r_row)) == int(r_row)
+            if diag:
+                assert tile * cpt <= c0 and c0 + cnt <= min((tile + 1) * cpt, chunks)
+                w += cnt * 48                      # one-sided body cost
+            else:
+                assert c0 >= (tile + 1) * cpt
+                w += cnt * 56                      # symmetric body cost
+            cover[tile, c0:c0 + cnt] += 1
+        assert sorted(rrow_of.values()) == list(range(len(rrow_of)))
+        work.append(w)
+    for tile in range(tiles):
+        first = tile * cpt
+        assert (cover[tile, first:] == 1).all(), tile      # own chunks (diagonal) and every later chunk: once
+        assert (cover[tile, :first] == 0).all(), tile      # earlier chunks belong to the earlier tile's items
+    if world > 1:
+        assert max(work) / (sum(work) / world) < 1.03       # snake dealing: within 3 % of the mean
+
+
+def test_plan_fills_the_chip():
+    for n, world, lo, hi in ((262144, 1, 6000, 10000), (262144, 8, 3000, 5000), (16384, 1, 1000, 1400)):
+        items, L = plan(n, world // 2, world)
+        assert lo <= len(items) <= hi, (n, world, len(items), L)
+
+
+def test_plan_rejects_bad_arguments():
+    lib = nb.load()
+    cnt = C.c_uint32()
+    assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, 0, C.byref(cnt), None) != 0
+    assert lib.nb_debug_sym_plan(1000, 256, 3, 2, None, 0, C.byref(cnt), None) != 0
