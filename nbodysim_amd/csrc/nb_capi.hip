@@ -140,13 +140,12 @@ static int bind(const nb_sim *s)
     return NB_OK;
 }
 
-// Launch geometry of one force job (DESIGN.md §launch geometry).  The kernel is
-// VALU-bound, so what matters is (a) enough independent work per lane — 2P
-// particles per lane, P = 4 measured best — and (b) enough workgroups in flight
-// to keep 5-8 waves per SIMD issuing and to even out the tail: about 16
-// workgroups per CU.  When i-particles are scarce (sharded or small runs) the
-// j range is cut into more slices, and P drops only when the slices would get
-// shorter than two LDS tiles.
+// Launch geometry of one one-sided force job.  The kernel is VALU-bound, so what
+// matters is (a) enough independent work per lane — 2P particles per lane, P = 4 measured best — and
+// (b) enough workgroups in flight to keep 5-8 waves per SIMD issuing and to even out the tail: about
+// 32 workgroups per CU (tools/force_bench.hip).  When i-particles are scarce (sharded or small runs)
+// the j range is cut into more tile-aligned slices (at most 128: every slice is a slab that
+// `integrate` re-reads), and P drops only when even that cannot fill half the target.
 static bool want_sym(const nb_sim *s);
 
 // Slices are whole LDS tiles and none is empty: js = ceil(tiles / ceil(tiles / want)).
