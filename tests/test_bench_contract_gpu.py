@@ -1,0 +1,49 @@
+"""GPU: bench.py prints exactly one JSON line with the fields the driver and the judge read."""
+import json
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def run_bench(*extra):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *extra], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = run_bench("--n", "32768", "--steps", "4", "--warmup", "1")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "pair interactions/s"
+    assert abs(d["value"] - 32768.0 ** 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf
+    assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["launches"] == 4 and rf["avg_launch_ms"] > 0          # HIP events around every force launch of the timed region
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert abs(d["energy"]["rel_drift"]) < 1e-3
+
+
+def test_bench_fp64_and_3d_variants_run():
+    d = run_bench("--n", "16384", "--steps", "2", "--warmup", "1", "--precision", "fp64", "--no-cpu-baseline")
+    assert d["dtype"] == "f64" and d["roofline"]["peak"] == 157.3 / 2 and "cpu_baseline" not in d
+    d = run_bench("--n", "16384", "--steps", "2", "--warmup", "1", "--dims", "3", "--no-cpu-baseline")
+    assert d["config"]["dims"] == 3 and d["roofline"]["flop_per_pair"] == 20.0
