@@ -11,6 +11,8 @@ Fixtures (little-endian float32 .npy, columns x,y,vx,vy,ax,ay,mass,radius):
   ref_direct_s{1,10,100}.npy REF-DIRECT states (reference Quadtree::acc leaf loop as a
                              direct sum + kick/drift), eps 0.05, dt 1e-3
   ref_step_s{1,10,100}.npy   REF-STEP states (production Simulation::step(), BH theta=1)
+  ic_extras_512.npy, ref_step_extras_s{1,4}.npy   massless far-out fast bodies through the real step():
+                             pins the velocity clamp and soft boundary of iterate() (Simulation.hpp:133-155)
   ref_direct_acc_{1024,4096}.npy   single REF-DIRECT force evaluation (n,2)
   ref_direct_acc_eps1_1024.npy     same with the reference's default eps = 1
   fast_inv_sqrt_x.npy / _y.npy     Quadtree::fast_inv_sqrt on a fixed 4096-point grid
@@ -77,6 +79,21 @@ def main() -> None:
         a = np.ascontiguousarray(ic.copy())
         ref.ref_direct_acc(a, a.shape[0], eps)
         out[name] = np.ascontiguousarray(a[:, 4:6])
+
+    # The non-gravity parts of Simulation::iterate (velocity clamp :133-137, soft boundary :140-155)
+    # pinned against the REAL step(): with every mass 0 the tree force is exactly 0 and radius 0 keeps
+    # collide() inert, so step() = kick(0) + clamp + boundary + drift.
+    rng = np.random.default_rng(20241223)
+    ex = np.zeros((512, 8), np.float32)
+    ang, rad = rng.uniform(0, 2 * np.pi, 512), rng.uniform(5e4, 1.4e5, 512)
+    ex[:, 0], ex[:, 1] = rad * np.cos(ang), rad * np.sin(ang)
+    ex[:, 2:4] = rng.normal(size=(512, 2)) * 900.0
+    out["ic_extras_512.npy"] = ex.copy()
+    for steps in (1, 4):
+        c = np.ascontiguousarray(ex.copy())
+        assert ref.ref_step(c, c.shape[0], 1.0, 0.01, steps) == steps
+        assert not c[:, 4:6].any()          # accelerations are exactly zero
+        out[f"ref_step_extras_s{steps}.npy"] = c
 
     x = np.concatenate([
         np.logspace(-12, 12, 2048).astype(np.float32),

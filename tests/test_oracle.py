@@ -155,3 +155,18 @@ def test_live_reference_agrees_with_fixtures(gold, nbo):
     ref.ref_direct_acc(g0, g0.shape[0], 0.0)
     ax, ay = nbo.accel_f32(nbo.state_from_flat(f), 0.0, nbo.RSQRT_QUAKE)
     assert np.array_equal(bits(ax), bits(g0[:, 4])) and np.array_equal(bits(ay), bits(g0[:, 5]))
+
+
+@pytest.mark.parametrize("steps", [1, 4])
+def test_extras_bit_exact_vs_real_reference_step(gold, nbo, steps):
+    """Velocity clamp and soft boundary (Simulation.hpp:133-155) against the reference's own step():
+    massless bodies feel no force, so step() reduces to kick(0) + clamp + boundary + drift."""
+    st = nbo.state_from_flat(gold["ic_extras_512"])
+    for _ in range(steps):
+        nbo.lib().nbo_kick_drift_f32(512, st["x"], st["y"], st["vx"], st["vy"], st["ax"], st["ay"], 0.01, 1)
+    got = nbo.state_to_flat(st)
+    want = gold[f"ref_step_extras_s{steps}"]
+    assert np.array_equal(bits(got[:, 0:4]), bits(want[:, 0:4]))
+    # the fixture really exercises both branches
+    ic = gold["ic_extras_512"]
+    assert (np.hypot(ic[:, 2], ic[:, 3]) > 1000).sum() > 50 and (np.hypot(ic[:, 0], ic[:, 1]) > 8e4).sum() > 100

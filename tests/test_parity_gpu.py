@@ -471,3 +471,15 @@ def test_full_size_properties(n):
     assert np.max(np.abs(acc8 - acc)) < 2e-5 * np.max(np.abs(acc))
     # virial ratio of the projected Plummer model stays put over 5 steps
     assert abs(k1 / abs(u1) - k0 / abs(u0)) < 1e-3
+
+
+def test_extras_vs_real_reference_step_golden(gold):
+    """GPU clamp + soft boundary against the golden produced by the reference's own step() on massless
+    bodies (pure iterate() extras).  expf differs in the last ulp between glibc and the device: 1e-6."""
+    ic = bodies_from_flat(gold["ic_extras_512"])
+    with nb.Simulation(ic, eps=1.0, rsqrt="quake", order="sequential", extras=3) as sim:
+        sim.advance(4, 0.01)
+        got = flat_from_bodies(sim.sync())
+    want = gold["ref_step_extras_s4"]
+    assert max_rel(got[:, 0:2], want[:, 0:2]) < 1e-6 and max_rel(got[:, 2:4], want[:, 2:4]) < 1e-6
+    assert not got[:, 4:6].any()
