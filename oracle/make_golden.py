@@ -18,6 +18,7 @@ Fixtures (little-endian float32 .npy, columns x,y,vx,vy,ax,ay,mass,radius):
   fast_inv_sqrt_x.npy / _y.npy     Quadtree::fast_inv_sqrt on a fixed 4096-point grid
   layout.json                sizeof/alignof/offsetof of the compiled Body / Vec2
   default_ics.json           digest + first/last bodies of Simulation()'s own 25 000-body ICs
+  default_ics_first4096.npy  the innermost 4096 of those bodies (1e9 central mass, |v| up to 1426 > the 1000 clamp)
   manifest.json              build flags, compiler, sha256 of every fixture
 """
 from __future__ import annotations
@@ -124,6 +125,10 @@ def main() -> None:
         "note": "libstdc++-specific (std::uniform_real_distribution), SURVEY.md §8c",
     }
     (GOLD / "default_ics.json").write_text(json.dumps(defaults, indent=1) + "\n")
+    # the innermost 4096 bodies of the reference's own demo ICs (sorted by radius, Simulation.hpp:585-589;
+    # body 0 is the 1e9 central mass): data for running the reference's default workload through the GPU path
+    np.save(GOLD / "default_ics_first4096.npy", np.ascontiguousarray(ics[:4096]))
+    out["default_ics_first4096.npy"] = ics[:4096]
 
     gxx = subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
     manifest = {

@@ -483,3 +483,39 @@ def test_extras_vs_real_reference_step_golden(gold):
     want = gold["ref_step_extras_s4"]
     assert max_rel(got[:, 0:2], want[:, 0:2]) < 1e-6 and max_rel(got[:, 2:4], want[:, 2:4]) < 1e-6
     assert not got[:, 4:6].any()
+
+
+def test_reference_default_workload_through_the_gpu_path(gold, nbo):
+    """The reference's own demo data (innermost 4096 bodies of uniform_disc: a 1e9 central mass, radii
+    cbrt(m), speeds above the 1000 clamp) with the reference's parameters (eps = 1, dt = 0.01, clamp and
+    boundary on), in the reference's arithmetic and summation order: the GPU must follow the restatement
+    bit for bit (no body is far enough out here for the boundary's expf to run)."""
+    flat = gold["default_ics_first4096"]
+    assert flat[0, 6] == 1e9 and (np.hypot(flat[:, 2], flat[:, 3]) > 1000).any()
+    assert np.hypot(flat[:, 0], flat[:, 1]).max() < 8e4
+    with nb.Simulation(bodies_from_flat(flat), eps=1.0, rsqrt="quake", order="sequential", extras=3) as sim:
+        sim.advance(5, 0.01)
+        got = flat_from_bodies(sim.sync())
+    st = nbo.step_f32(nbo.state_from_flat(flat), 1.0, 0.01, 5, nbo.RSQRT_QUAKE, 1)
+    want = nbo.state_to_flat(st)
+    assert np.array_equal(bits(got[:, 0:6]), bits(want[:, 0:6]))
+    assert (np.hypot(got[:, 2], got[:, 3]) <= 1000.0 * (1 + 1e-6)).all()
+    assert np.array_equal(got[:, 7], flat[:, 7])          # radius carried through untouched
+
+
+def test_long_run_conserves_energy_and_momentum():
+    """1000 kick-drift steps at N = 4096: the symplectic map keeps the energy error bounded and the
+    pairwise-antisymmetric force keeps the total momentum where it started."""
+    ic = nb.plummer_2d(4096, 77)
+    m = ic["mass"].astype(np.float64)[:, None]
+    p0 = (m * ic["vel"]).sum(0)
+    with nb.Simulation(ic, eps=0.05) as sim:
+        k0, u0 = sim.energy()
+        worst = 0.0
+        for _ in range(10):
+            sim.advance(100, 1e-3)
+            k, u = sim.energy()
+            worst = max(worst, abs((k + u - k0 - u0) / (k0 + u0)))
+        b = sim.sync()
+    assert worst < 2e-3
+    assert np.abs((m * b["vel"]).sum(0) - p0).max() < 1e-5 * np.abs(m * b["vel"]).sum(0).max()
