@@ -87,8 +87,14 @@ def main() -> None:
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses the multi-rank path on a one-GPU box")
+    ap.add_argument("--protocol", default="auto", choices=["auto", "symmetric", "allgather"],
+                    help="multi-GPU exchange: symmetric pair split (reduce-scatter + all-gather, default where eligible) or the "
+                         "one-sided all-gather protocol (all-gather overlapped with the local-tile force)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     args = ap.parse_args()
+
+    if args.protocol == "allgather":
+        os.environ["NB_NO_SYMMETRY"] = "1"      # read by the library at nb_create: one-sided kernels, all-gather protocol
 
     import torch
 
