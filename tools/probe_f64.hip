@@ -91,6 +91,5 @@ int main()
     }
     printf("v_rsq_f64 max rel err: raw %.3e   +1 Newton %.3e   +3rd-order %.3e   (eps_f64 = 1.1e-16)\n", e0, e1, e3);
     rate<0>("v_fma_f64"); rate<2>("v_mul_f64"); rate<3>("v_add_f64"); rate<1>("v_rsq_f64");
-    rate<6>("v_fma_f32"); rate<5>("v_pk_fma_f32"); rate<4>("v_rsq_f32");
     return 0;
 }
