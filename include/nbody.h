@@ -223,11 +223,13 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *   NB_SHARD_ALLGATHER   (i_count < n): begin = local-tile force; host all-gathers the positions
  *                        into nb_pos_buffer(CURRENT) (may overlap begin); finish = remote force,
  *                        kick, drift.  One-sided kernels; one collective per step.
- *   NB_SHARD_SYMMETRIC   (shard_world > 1, fp32 tiled, eps > 0, large n): every rank evaluates a
- *                        balanced share of the UNORDERED pairs with the symmetric kernel:
- *                        begin = partial acceleration of ALL particles into nb_acc_buffer(0);
- *                        host reduce-scatters it (sum) into nb_acc_buffer(1); finish = kick, drift
- *                        of the owned block; host all-gathers positions before the next begin. */
+ *   NB_SHARD_SYMMETRIC   (shard_world > 1, tiled, eps > 0, large n, equal blocks of whole 2048-particle
+ *                        tiles): every rank evaluates 1/world of the UNORDERED pairs with the symmetric
+ *                        kernel: begin = the pairs inside its own block (overlaps the all-gather still in
+ *                        flight); host waits for the all-gather; nb_step_mid = its share of the cross-block
+ *                        pairs, then the partial acceleration of ALL particles into nb_acc_buffer(0); host
+ *                        reduce-scatters it (sum) into nb_acc_buffer(1); finish = kick, drift of the owned
+ *                        block; host starts the all-gather of the new positions. */
 enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2 };
 int   nb_shard_protocol(const nb_sim *s);
 /* Exchange for a host that drives SEVERAL sharded handles from one process (e.g. one per GPU of
@@ -238,6 +240,7 @@ int   nb_shard_protocol(const nb_sim *s);
 int   nb_exchange_positions(nb_sim *const *sims, int count);
 void *nb_acc_buffer(nb_sim *s, int which);   /* 0: full-n partial, 1: owned block sum (NULL if unused) */
 int   nb_step_begin(nb_sim *s, float dt);
+int   nb_step_mid(nb_sim *s);      /* NB_SHARD_SYMMETRIC only (no-op otherwise): see below */
 int   nb_step_finish(nb_sim *s);
 void *nb_pos_buffer(nb_sim *s, int which);   /* device pointer, n*(x,y) reals */
 void *nb_stream(nb_sim *s);                  /* hipStream_t in use */
@@ -263,9 +266,10 @@ int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
 /* Host-only view of the symmetric kernel's work planner (no GPU needed; used by the CPU tests to check
  * that the items of all ranks cover every unordered (tile, chunk) pair exactly once and are balanced).
  * items_out receives up to cap items of 8 uint32: tile, first chunk, chunk count, stationary slab row,
- * travelling slab row, diagonal flag, 0, 0.  Tiles are 2048 particles, chunks 64. */
+ * travelling slab row, diagonal flag, 0, 0; the first *n_local items are the rank's LOCAL items (pairs
+ * inside its own block), the rest its run of cross-block items.  Tiles are 2048 particles, chunks 64. */
 int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
-                      uint32_t *n_items, uint32_t *chunks_per_item);
+                      uint32_t *n_items, uint32_t *n_local, uint32_t *chunks_per_item);
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "nb_read_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(nb_params)]),
     "nb_read_bodies": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
     "nb_step_begin": (C.c_int, [C.c_void_p, C.c_float]),
+    "nb_step_mid": (C.c_int, [C.c_void_p]),
     "nb_step_finish": (C.c_int, [C.c_void_p]),
     "nb_pos_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_stream": (C.c_void_p, [C.c_void_p]),
@@ -117,7 +118,7 @@ PROTOTYPES = {
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
-    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),

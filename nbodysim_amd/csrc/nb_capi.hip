@@ -110,15 +110,17 @@ struct nb_sim {
     uint64_t frame = 0;
     float pending_dt = 0.f;
     bool in_step = false;
+    bool mid_done = false;          // symmetric sharded protocol: nb_step_mid has run for the step in flight
     bool acc_valid = false;         // KDK: acc holds a(x_cur)
     bool uniform_mass = false;      // every body has the same mass: the per-pair mass multiply is hoisted
     float um_mass = 0.f;
 
     // symmetric path (force_sym_f32): work items and its two slab sets
     bool sym = false;
-    uint32_t sym_items = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0;
-    SymItem *sym_items_dev = nullptr;
-    uint32_t *sym_rowbase_dev = nullptr, *sym_tile_row_dev = nullptr;
+    uint32_t sym_items = 0, sym_items_local = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_nsegs = 0;
+    SymItem *sym_items_dev = nullptr;          // local items first, then the cross-block items
+    uint32_t *sym_rowbase_dev = nullptr;
+    SymSeg *sym_segs_dev = nullptr;
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
@@ -217,7 +219,8 @@ static bool sym_eligible(const nb_sim *s)
     if (s->n < 8 * (size_t)SYM_SB) return false;
     const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
     const size_t world = s->p.shard_world > 1 ? (size_t)s->p.shard_world : 1;
-    if ((tiles + world - 1) / world * s->n * s->esz > ((size_t)8 << 30)) return false;   // travelling slab cap: 8 GiB
+    const size_t rrows = world == 1 ? tiles : 2 * tiles / world + 2;            // travelling rows held by one handle
+    if (rrows * s->n * s->esz > ((size_t)8 << 30)) return false;                   // slab cap: 8 GiB
     return true;
 }
 
@@ -228,71 +231,110 @@ static bool want_sym(const nb_sim *s)          // single handle owns everything
 
 static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
 {
-    return s->p.shard_world > 1 && s->i_count != s->n && sym_eligible(s) &&
-           s->n / (size_t)s->p.shard_world >= 2 * (size_t)SYM_SB;
+    const size_t w = (size_t)s->p.shard_world;
+    return s->p.shard_world > 1 && s->i_count != s->n && sym_eligible(s) && s->n / w >= 2 * (size_t)SYM_SB &&
+           s->n % (w * SYM_SB) == 0 && s->i_count == s->n / w && s->i_begin == (size_t)s->p.shard_rank * s->i_count;   // equal blocks of whole tiles
 }
 
-// Tiles are dealt to ranks in snake order (0..W-1, W-1..0, ...): tile I costs ~(T - I) units, so
-// consecutive rounds in opposite directions give every rank the same total to within one tile.
-static uint32_t tile_owner(uint32_t I, uint32_t world)
-{
-    const uint32_t round = I / world, k = I % world;
-    return (round & 1u) ? world - 1 - k : k;
-}
-
-// Pure planner of the symmetric scheme (no device calls; also behind nb_debug_sym_plan for the CPU tests):
-// the work items of `rank`, the first slab_s row of every tile (rowbase, tiles + 1 entries) and the slab_r
-// row of every tile (SYM_NONE for tiles dealt to other ranks).  Returns chunks per item.
+// Pure planner of the symmetric scheme (no device calls; also behind nb_debug_sym_plan for the CPU tests).
+// The particle range is cut into `world` equal blocks (block r is integrated by rank r; blocks are whole
+// tiles).  Rank r evaluates
+//   LOCAL items  every unordered pair INSIDE its own block: the diagonal items of its tiles and the
+//                symmetric items whose chunks lie in the same block — they need only positions the rank
+//                has just produced itself, so they run while the all-gather of the other blocks is in flight;
+//   CROSS items  an equal share of the pairs between different blocks: the ordered list of all
+//                (tile I, L-chunk slice after I's block) items is cut into `world` runs of equal work.
+// Outputs: the items of `rank` (n_local local ones first), the first slab_s row of every tile (rowbase,
+// tiles + 1 entries; a tile's rows are its local items then its cross items) and the slab_r row segments
+// (row, particle range) the rank's items write.  Returns the chunks per item, L.
 static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, uint32_t forced_L,
-                               std::vector<SymItem> &items, std::vector<uint32_t> &rowbase, std::vector<uint32_t> &tile_row)
+                               std::vector<SymItem> &items, uint32_t &n_local, std::vector<uint32_t> &rowbase,
+                               std::vector<SymSeg> &segs)
 {
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
-    // chunks strictly after tile I: chunks - (I+1)*cpt (>= 0); only this rank's tiles count
-    uint64_t total = 0;
+    const uint32_t tpb = world > 1 ? (n / world) / SYM_SB : tiles;                 // tiles per block
+    auto block_end_chunk = [&](uint32_t I) {                                       // first chunk after I's block
+        const uint32_t e = (I / tpb + 1) * tpb * cpt;
+        return (world > 1 && e < chunks) ? e : chunks;
+    };
+    // work (in chunks) of this rank: its local pairs + 1/world of the cross pairs
+    uint64_t local = 0, cross_total = 0;
     for (uint32_t I = 0; I < tiles; ++I) {
-        if (tile_owner(I, world) != rank) continue;
-        const uint32_t first = (I + 1) * cpt;
-        if (first < chunks) total += chunks - first;
+        const uint32_t be = block_end_chunk(I);
+        if (I / tpb == rank || world == 1) local += be - I * cpt;                 // own chunks (diagonal) + later chunks of the block
+        cross_total += chunks - be;
     }
-    // ~32 workgroups per CU on a single GPU, ~16 on a sharded rank, whose items are shorter
-    // (profiles/r01_shard_sym_per_rank_sweep.log: L = 8 beats L = 4 at an 8-way split)
-    const uint32_t target = (world > 1 ? 16u : 32u) * cus;
-    uint32_t L = forced_L ? forced_L : (uint32_t)((total + target - 1) / target);
+    const uint32_t target = (world > 1 ? 16u : 32u) * cus;                        // workgroups wanted (profiles/r01_*sweep.log)
+    uint32_t L = forced_L ? forced_L : (uint32_t)((local + cross_total / world + target - 1) / target);
     if (L < 1) L = 1;
-    items.clear();
+
+    // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
+    std::vector<SymItem> local_items, cross_items;
+    std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0);
+    std::vector<uint32_t> cross_lo(tiles, 0xffffffffu), cross_hi(tiles, 0);
+    uint64_t cum = 0;
+    for (uint32_t I = 0; I < tiles; ++I) {
+        const uint32_t be = block_end_chunk(I);
+        if (I / tpb == rank || world == 1) {
+            const uint32_t d0 = I * cpt, dend = (I + 1) * cpt < chunks ? (I + 1) * cpt : chunks;
+            for (uint32_t c = d0; c < dend; c += L) {                               // diagonal, one-sided
+                local_items.push_back(SymItem{I, c, dend - c < L ? dend - c : L, 0u, 0u, 1u, 0u, 0u});
+                ++local_rows_of[I];
+            }
+            for (uint32_t c = dend; c < be; c += L) {                               // rest of the block, symmetric
+                local_items.push_back(SymItem{I, c, be - c < L ? be - c : L, 0u, 0u, 0u, 0u, 0u});
+                ++local_rows_of[I];
+            }
+        }
+        for (uint32_t c = be; c < chunks; c += L) {                                 // later blocks
+            const uint32_t cnt = chunks - c < L ? chunks - c : L;
+            const uint32_t owner = cross_total ? (uint32_t)((cum * world) / cross_total) : 0u;
+            if (owner == rank) {
+                cross_items.push_back(SymItem{I, c, cnt, 0u, 0u, 0u, 0u, 0u});
+                ++cross_rows_of[I];
+                if (c < cross_lo[I]) cross_lo[I] = c;
+                if (c + cnt > cross_hi[I]) cross_hi[I] = c + cnt;
+            }
+            cum += cnt;
+        }
+    }
+    // slab rows: a tile's stationary rows are contiguous (local items, then cross items); one travelling
+    // row per (tile, part) with the particle range that part covers
     rowbase.assign(tiles + 1, 0);
-    tile_row.assign(tiles, SYM_NONE);
+    segs.clear();
+    std::vector<uint32_t> next_local(tiles), next_cross(tiles), seg_local(tiles, 0), seg_cross(tiles, 0);
     uint32_t row = 0, rrow = 0;
     for (uint32_t I = 0; I < tiles; ++I) {
         rowbase[I] = row;
-        if (tile_owner(I, world) != rank) continue;
-        tile_row[I] = rrow;
-        // diagonal items (tile I against its own chunks, one-sided), cut like the symmetric ones so
-        // that no single workgroup becomes the critical path at small n
-        const uint32_t d0 = I * cpt, dcnt = chunks - d0 < cpt ? chunks - d0 : cpt;
-        for (uint32_t c = 0; c < dcnt; c += L) {
-            const uint32_t cnt = dcnt - c < L ? dcnt - c : L;
-            items.push_back(SymItem{I, d0 + c, cnt, row++, rrow, 1u, 0u, 0u});
-        }
-        for (uint32_t c0 = (I + 1) * cpt; c0 < chunks; c0 += L) {
-            const uint32_t cnt = chunks - c0 < L ? chunks - c0 : L;
-            items.push_back(SymItem{I, c0, cnt, row++, rrow, 0u, 0u, 0u});
-        }
-        ++rrow;
+        next_local[I] = row; row += local_rows_of[I];
+        next_cross[I] = row; row += cross_rows_of[I];
+        const uint32_t be = block_end_chunk(I), dend = (I + 1) * cpt < chunks ? (I + 1) * cpt : chunks;
+        if ((I / tpb == rank || world == 1) && be > dend) { seg_local[I] = rrow; segs.push_back(SymSeg{rrow++, dend * SYM_CH, be * SYM_CH, I}); }
+        if (cross_rows_of[I]) { seg_cross[I] = rrow; segs.push_back(SymSeg{rrow++, cross_lo[I] * SYM_CH, cross_hi[I] * SYM_CH, I}); }
     }
     rowbase[tiles] = row;
+    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_row = seg_local[it.tile]; }
+    for (auto &it : cross_items) { it.s_row = next_cross[it.tile]++; it.r_row = seg_cross[it.tile]; }
+    n_local = (uint32_t)local_items.size();
+    items = std::move(local_items);
+    items.insert(items.end(), cross_items.begin(), cross_items.end());
     return L;
 }
 
-// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag, 0, 0).
+// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag, 0, 0);
+// the first *n_local of them are the rank's local items.
 extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
-                                 uint32_t *n_items, uint32_t *chunks_per_item)
+                                 uint32_t *n_items, uint32_t *n_local, uint32_t *chunks_per_item)
 {
-    if (n == 0 || n > 0x7fffff00u || cus < 1 || world < 1 || rank < 0 || rank >= world) { nb_set_error("nb_debug_sym_plan: bad arguments"); return NB_EINVAL; }
+    if (n == 0 || n > 0x7fffff00u || cus < 1 || world < 1 || rank < 0 || rank >= world ||
+        (world > 1 && (n % ((size_t)world * SYM_SB)) != 0)) { nb_set_error("nb_debug_sym_plan: bad arguments"); return NB_EINVAL; }
     std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase, tile_row;
-    const uint32_t L = build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, items, rowbase, tile_row);
+    std::vector<uint32_t> rowbase;
+    std::vector<SymSeg> segs;
+    uint32_t nl = 0;
+    const uint32_t L = build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, items, nl, rowbase, segs);
     if (n_items) *n_items = (uint32_t)items.size();
+    if (n_local) *n_local = nl;
     if (chunks_per_item) *chunks_per_item = L;
     if (items_out) memcpy(items_out, items.data(), (items.size() < cap ? items.size() : cap) * sizeof(SymItem));
     return NB_OK;
@@ -306,20 +348,22 @@ static int plan_sym(nb_sim *s)
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB;
     const char *envl = getenv("NB_SYM_L");
     std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase, tile_row;
-    const uint32_t L = build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u, items, rowbase, tile_row);
-    const uint32_t row = rowbase[tiles];
-    uint32_t rrow = 0;
-    for (uint32_t r : tile_row) if (r != SYM_NONE) ++rrow;
+    std::vector<uint32_t> rowbase;
+    std::vector<SymSeg> segs;
+    uint32_t n_local = 0;
+    const uint32_t L = build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u,
+                                      items, n_local, rowbase, segs);
+    const uint32_t row = rowbase[tiles], rrow = (uint32_t)segs.size();
+    s->sym_items_local = n_local; s->sym_nsegs = rrow;
     s->sym_items = (uint32_t)items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = L;
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&s->sym_tile_row_dev, tile_row.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&s->sym_segs_dev, (segs.size() ? segs.size() : 1) * sizeof(SymSeg)));
     HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
     HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * s->esz));
     HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_tile_row_dev, tile_row.data(), tile_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_segs_dev, segs.data(), segs.size() * sizeof(SymSeg), hipMemcpyHostToDevice));
     if (s->sym_sharded) {
         if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
         else {
@@ -341,7 +385,7 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->mass); (void)hipFree(s->radius);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
     (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
-    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_tile_row_dev);
+    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_segs_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
     if (s->staging) (void)hipHostFree(s->staging);
@@ -546,84 +590,96 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
         (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, j.gap_begin, j.gap_len);
 }
 
-// Force through the symmetric kernel over the items held by this handle.  Unsharded: leaves the
-// summed acceleration in slab 0.  Sharded: leaves this rank's partial acceleration of ALL particles
-// in acc_full (the host reduce-scatters it into acc_owned).
-static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
+// Symmetric kernel over items [first, first + count) of this handle (HIP events around the launch
+// when profiling).
+static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count)
 {
+    if (count == 0) return NB_OK;
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
     const uint32_t n = (uint32_t)s->n;
-    void *dst = s->sym_sharded ? s->acc_full : s->partial;
-    const int nxt = s->cur ^ 1;
-    const int kd = INTEG_KICK | INTEG_DRIFT;
+    const SymItem *items = s->sym_items_dev + first;
+    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
     if (s->dims3) {
         const float eps2 = s->p.eps * s->p.eps;
         const float4 *pos = (const float4 *)s->pos[s->cur];
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
-        const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
         if (s->uniform_mass) {
-            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
-            else       force_sym3_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
+            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, s->um_mass);
+            else       force_sym3_f32<RSQ_EXACT, true><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, s->um_mass);
         } else {
-            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
-            else       force_sym3_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
+            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, 1.0f);
+            else       force_sym3_f32<RSQ_EXACT, false><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, 1.0f);
         }
-        HIPCHK(hipGetLastError());
-        if (s->prof && prof_end(s, pr)) return NB_EHIP;
-        const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
-        if (fuse_step)
-            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float4 *)dst, pos, (float4 *)s->pos[nxt],
-                                                           (float4 *)s->vel, (float4 *)s->acc, (float)dt, (float)dt, kd);
-        else
-            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float4 *)dst, nullptr, nullptr,
-                                                            nullptr, nullptr, 0.f, 0.f, 0);
-        HIPCHK(hipGetLastError());
-        return NB_OK;
-    }
-    if (s->fp64) {
+    } else if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
         const double *mass = (const double *)s->mass;
-        if (s->uniform_mass) force_sym_f64<true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
-        else                 force_sym_f64<false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
-        HIPCHK(hipGetLastError());
-        if (s->prof && prof_end(s, pr)) return NB_EHIP;
-        const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
-        if (fuse_step)
-            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, s->sym_rowbase_dev,
-                                                                  s->sym_tile_row_dev, n, (double2 *)dst, (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt],
-                                                                  (double2 *)s->vel, (double2 *)s->acc, dt, dt, s->p.extras, kd);
-        else
-            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, s->sym_rowbase_dev,
-                                                                   s->sym_tile_row_dev, n, (double2 *)dst, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
-        HIPCHK(hipGetLastError());
-        return NB_OK;
-    }
-    const float eps2 = s->p.eps * s->p.eps;
-    const float2 *pos = (const float2 *)s->pos[s->cur];
-    const float *mass = (const float *)s->mass;
-    float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
-    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
-    if (s->uniform_mass) {
-        if (quake) force_sym_f32<RSQ_QUAKE, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
-        else       force_sym_f32<RSQ_EXACT, true><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, s->um_mass);
+        if (s->uniform_mass) force_sym_f64<true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
+        else                 force_sym_f64<false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
     } else {
-        if (quake) force_sym_f32<RSQ_QUAKE, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
-        else       force_sym_f32<RSQ_EXACT, false><<<s->sym_items, BLOCK, 0, s->stream>>>(pos, mass, s->sym_items_dev, ss, sr, n, eps2, 1.0f);
+        const float eps2 = s->p.eps * s->p.eps;
+        const float2 *pos = (const float2 *)s->pos[s->cur];
+        const float *mass = (const float *)s->mass;
+        float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
+        if (s->uniform_mass) {
+            if (quake) force_sym_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
+            else       force_sym_f32<RSQ_EXACT, true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
+        } else {
+            if (quake) force_sym_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
+            else       force_sym_f32<RSQ_EXACT, false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
+        }
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    const uint32_t gg = (n + GATHER_P - 1) / GATHER_P;
-    if (fuse_step)
-        sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst,
-                                                             (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
-                                                             (float)dt, (float)dt, s->p.extras, kd);
-    else
-        sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_tile_row_dev, n, (float2 *)dst,
-                                                              nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
+    return NB_OK;
+}
+
+// Sum of the slabs.  fuse_step (whole-system handles): apply kick and drift in the same kernel; otherwise the
+// summed (unsharded) or partial (sharded rank) acceleration of every particle is stored: slab 0 / acc_full.
+static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
+{
+    const uint32_t n = (uint32_t)s->n, gg = (n + GATHER_P - 1) / GATHER_P;
+    void *dst = s->sym_sharded ? s->acc_full : s->partial;
+    const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
+    if (s->dims3) {
+        const float4 *ss = (const float4 *)s->sym_slab_s, *sr = (const float4 *)s->sym_slab_r;
+        if (fuse_step)
+            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+                                                           (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                           (float)dt, (float)dt, kd);
+        else
+            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+                                                            nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0);
+    } else if (s->fp64) {
+        const double2 *ss = (const double2 *)s->sym_slab_s, *sr = (const double2 *)s->sym_slab_r;
+        if (fuse_step)
+            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (double2 *)dst,
+                                                                  (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
+                                                                  dt, dt, s->p.extras, kd);
+        else
+            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (double2 *)dst,
+                                                                   nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
+    } else {
+        const float2 *ss = (const float2 *)s->sym_slab_s, *sr = (const float2 *)s->sym_slab_r;
+        if (fuse_step)
+            sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float2 *)dst,
+                                                                 (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
+                                                                 (float)dt, (float)dt, s->p.extras, kd);
+        else
+            sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float2 *)dst,
+                                                                  nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
+    }
     HIPCHK(hipGetLastError());
     return NB_OK;
+}
+
+// Whole-system symmetric force (+ optionally the kick/drift).
+static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
+{
+    int rc = launch_sym_items(s, 0, s->sym_items);
+    if (rc) return rc;
+    return launch_sym_gather(s, fuse_step, dt);
 }
 
 static int launch_force(nb_sim *s, const ForceJob &j)
@@ -727,10 +783,23 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     s->in_step = true;
-    if (s->sym_sharded) return launch_force_sym(s);   // partial acceleration of every particle
+    if (s->sym_sharded) return launch_sym_items(s, 0, s->sym_items_local);   // pairs inside my own block: no remote data needed
     // local j-block first: its positions are already resident, so this overlaps the exchange
     if (two_phase(s)) return launch_force(s, s->job_local);
     return NB_OK;
+}
+
+extern "C" int nb_step_mid(nb_sim *s)
+{
+    if (!s) { nb_set_error("nb_step_mid: NULL handle"); return NB_EINVAL; }
+    if (!s->in_step) { nb_set_error("nb_step_mid: no step in flight"); return NB_ESTATE; }
+    if (!s->sym_sharded) return NB_OK;                 // nothing between begin and finish in the other protocols
+    if (s->mid_done) { nb_set_error("nb_step_mid: already called for this step"); return NB_ESTATE; }
+    if (bind(s)) return NB_EHIP;
+    int rc = launch_sym_items(s, s->sym_items_local, s->sym_items - s->sym_items_local);   // cross-block pairs: need the gathered positions
+    if (rc) return rc;
+    s->mid_done = true;
+    return launch_sym_gather(s, false, 0.0);           // partial acceleration of every particle -> acc_full
 }
 
 extern "C" int nb_step_finish(nb_sim *s)
@@ -742,6 +811,8 @@ extern "C" int nb_step_finish(nb_sim *s)
     int rc;
     uint32_t nslabs;
     if (s->sym_sharded) {
+        if (!s->mid_done) { s->in_step = true; nb_set_error("nb_step_finish: symmetric sharded handle needs nb_step_mid (and the reduce-scatter) first"); return NB_ESTATE; }
+        s->mid_done = false;
         // the host has reduce-scattered acc_full into acc_owned: it is the one slab of the owned block
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
         const int nxt = s->cur ^ 1;

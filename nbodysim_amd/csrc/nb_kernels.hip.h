@@ -362,9 +362,9 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 //   slab_R[r][n]        travelling partials: the force of tile I (row r = item.r_row) on
 //                       particles after it
 // sym_gather adds, for particle k of tile g: its slab_S rows + slab_R[row(I)][k] for I < g.
-// A rank of a sharded run holds the items of the tiles it was dealt (tile_row[I] != NONE);
-// its gather then yields a PARTIAL acceleration for every particle, and the ranks' partials
-// are summed by the host's reduce-scatter.
+// A rank of a sharded run holds only its share of the items (its own block's internal pairs plus
+// an equal run of the cross-block items); its gather then yields a PARTIAL acceleration for every
+// particle, and the ranks' partials are summed by the host's reduce-scatter.
 // Requires eps > 0 (r = 0 then contributes exactly 0); eps == 0 uses force_tiled_f32<GUARD>.
 // ---------------------------------------------------------------------------
 struct SymItem { uint32_t tile, c0, cnt, s_row, r_row, diag, pad0, pad1; };   // 32 bytes
@@ -516,10 +516,11 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
     }
 }
 
-// acc_sum[k] = sum of particle k's stationary rows (its tile's items, in item order; none if the
-//              tile belongs to another rank: rowbase[g] == rowbase[g+1])
-//            + sum over earlier tiles I held here of slab_r[tile_row[I]][k]  (in tile order).
-constexpr uint32_t SYM_NONE = 0xffffffffu;
+// acc_sum[k] = sum of particle k's stationary rows (its tile's items held here, in item order;
+//              none if rowbase[g] == rowbase[g+1])
+//            + sum over the travelling-row segments held here that cover k (in segment order).
+// One row of slab_r and the particle range [lo, hi) it holds valid travelling sums for.
+struct SymSeg { uint32_t row, lo, hi, tile; };
 
 // 32 particles per workgroup, 8 threads per particle: thread (q, p) adds the rows r = q (mod 8)
 // of particle p's lists in ascending order, the 8 partials are then added in q order — a fixed
@@ -533,7 +534,7 @@ template <typename real, bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
                 const typename vec2_of<real>::type *__restrict__ slab_r,
-                const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row,
+                const uint32_t *__restrict__ rowbase, const SymSeg *__restrict__ segs, uint32_t nsegs,
                 uint32_t n, typename vec2_of<real>::type *__restrict__ acc_sum,
                 const typename vec2_of<real>::type *__restrict__ pos_cur,
                 typename vec2_of<real>::type *__restrict__ pos_next,
@@ -553,10 +554,10 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
             const real2 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y;
         }
-        for (uint32_t i = q; i < g; i += GATHER_Q) {
-            const uint32_t rr = tile_row[i];
-            if (rr == SYM_NONE) continue;
-            const real2 b = slab_r[(size_t)rr * n + k];
+        for (uint32_t i = q; i < nsegs; i += GATHER_Q) {
+            const SymSeg sg = segs[i];
+            if (k < sg.lo || k >= sg.hi) continue;
+            const real2 b = slab_r[(size_t)sg.row * n + k];
             a.x += b.x; a.y += b.y;
         }
     }

@@ -283,7 +283,7 @@ void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ 
 template <bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ slab_r,
-                 const uint32_t *__restrict__ rowbase, const uint32_t *__restrict__ tile_row, uint32_t n,
+                 const uint32_t *__restrict__ rowbase, const SymSeg *__restrict__ segs, uint32_t nsegs, uint32_t n,
                  float4 *__restrict__ acc_sum, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
                  float4 *__restrict__ vel, float4 *__restrict__ acc, float dt_kick, float dt_drift, int flags)
 {
@@ -297,10 +297,10 @@ void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ s
             const float4 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
-        for (uint32_t i = q; i < g; i += GATHER_Q) {
-            const uint32_t rr = tile_row[i];
-            if (rr == SYM_NONE) continue;
-            const float4 b = slab_r[(size_t)rr * n + k];
+        for (uint32_t i = q; i < nsegs; i += GATHER_Q) {
+            const SymSeg sg = segs[i];
+            if (k < sg.lo || k >= sg.hi) continue;
+            const float4 b = slab_r[(size_t)sg.row * n + k];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
     }

@@ -4,14 +4,17 @@ Each rank integrates one contiguous block of particles and holds a full-n replic
 of the positions (double buffered, in torch tensors so the collectives write them
 in place).  The library tells which exchange a handle needs (``nb_shard_protocol``):
 
-NB_SHARD_SYMMETRIC (fp32, eps > 0, large n — the benchmark case).  Every rank
-evaluates a balanced share of the UNORDERED pairs with the symmetric kernel (tiles
-dealt in snake order), which yields a partial acceleration for every particle:
+NB_SHARD_SYMMETRIC (eps > 0, large n — the benchmark case).  Every rank evaluates
+1/world of the UNORDERED pairs with the symmetric kernel — the pairs inside its own
+block plus an equal run of the cross-block pairs — which yields a partial
+acceleration for every particle:
 
-    [compute]  force_sym(my tiles) -> acc_partial[n] | reduce-scatter(sum) -> acc[my block] | kick, drift | all-gather(x,y)
+    [compute]  force_sym(pairs inside my block) | wait AG | force_sym(my cross-block run) -> acc_partial[n] | RS | kick, drift
+    [comm   ]  ... all-gather(x,y) of the previous step ...                                  reduce-scatter(sum)   \\-> all-gather
 
 two collectives per step (2 MiB each at N = 262 144, latency-bound), RCCL
-``reduce_scatter_tensor`` / ``all_gather_into_tensor`` over xGMI.
+``reduce_scatter_tensor`` / ``all_gather_into_tensor`` over xGMI; the all-gather is
+hidden behind the local pairs (1/world of the rank's work).
 
 NB_SHARD_ALLGATHER (everything else).  i-particles are independent: the only
 exchange is the all-gather of the drifted (x, y) blocks, overlapped with the
@@ -136,10 +139,11 @@ class DistributedSimulation:
         """One sharded step; only enqueues (no host sync)."""
         if self.symmetric:
             with self.torch.cuda.stream(self.stream):
+                self.sim.step_begin(dt)      # pairs inside my own block: overlaps the all-gather still in flight
                 if self._pending is not None:
                     self._pending.wait()     # every rank's new positions are in the CURRENT replica
                     self._pending = None
-                self.sim.step_begin(dt)      # symmetric force over my tiles -> partial acceleration of all n
+                self.sim.step_mid()          # my run of the cross-block pairs -> partial acceleration of all n
                 self._reduce_accelerations() # ordered after the force on this stream by the process group
                 self.sim.step_finish()       # kick, drift of my block -> NEXT becomes CURRENT
                 self._cur ^= 1

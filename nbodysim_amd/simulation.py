@@ -139,6 +139,9 @@ class Simulation:
     def step_begin(self, dt: Optional[float] = None) -> None:
         L.check("nb_step_begin", self._lib.nb_step_begin(self._h, SIMULATION_DT if dt is None else dt))
 
+    def step_mid(self) -> None:
+        L.check("nb_step_mid", self._lib.nb_step_mid(self._h))
+
     def step_finish(self) -> None:
         L.check("nb_step_finish", self._lib.nb_step_finish(self._h))
 

@@ -14,29 +14,37 @@ SB, CH = 2048, 64
 
 def plan(n, rank, world, cus=256):
     lib = nb.load()
-    cnt, L = C.c_uint32(), C.c_uint32()
-    assert lib.nb_debug_sym_plan(n, cus, rank, world, None, 0, C.byref(cnt), C.byref(L)) == 0
+    cnt, nloc, L = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert lib.nb_debug_sym_plan(n, cus, rank, world, None, 0, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
     items = np.zeros((cnt.value, 8), np.uint32)
-    assert lib.nb_debug_sym_plan(n, cus, rank, world, items.ctypes.data, cnt.value, C.byref(cnt), C.byref(L)) == 0
-    return items, int(L.value)
+    assert lib.nb_debug_sym_plan(n, cus, rank, world, items.ctypes.data, cnt.value, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
+    return items, int(nloc.value), int(L.value)
 
 
 @pytest.mark.parametrize("n,world", [(16384, 1), (20000, 1), (70001, 1), (262144, 1), (262144, 2), (262144, 4), (262144, 8),
-                                     (65536, 8), (1048576, 8), (100000, 3)])
+                                     (65536, 8), (1048576, 8), (196608, 3)])
 def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
     tiles, chunks, cpt = -(-n // SB), -(-n // CH), SB // CH
     cover = np.zeros((tiles, chunks), np.int32)
     work = []
+    blk_tiles = tiles if world == 1 else (n // world) // SB
     for rank in range(world):
-        items, L = plan(n, rank, world)
-        assert len(items) > 0 and L >= 1
-        # slab rows: stationary rows unique and dense per rank, travelling row constant per tile
+        items, nloc, L = plan(n, rank, world)
+        assert len(items) > 0 and L >= 1 and 0 < nloc <= len(items)
+        # slab rows: stationary rows unique and dense per rank; one travelling row per (tile, local|cross) part
         assert sorted(items[:, 3]) == list(range(len(items)))
         w = 0
         rrow_of = {}
-        for tile, c0, cnt, s_row, r_row, diag, _, _ in items:
+        for idx, (tile, c0, cnt, s_row, r_row, diag, _, _) in enumerate(items):
             assert 1 <= cnt <= L and c0 + cnt <= chunks
-            assert rrow_of.setdefault(int(tile), int(r_row)) == int(r_row)
+            local = idx < nloc
+            if local:   # pairs inside the rank's own block: tile and chunks both in block `rank`
+                assert tile // blk_tiles == rank or world == 1
+                assert c0 + cnt <= min((tile // blk_tiles + 1) * blk_tiles * cpt, chunks)
+            else:       # cross-block pairs: chunks strictly after the tile's block
+                assert not diag and c0 >= (tile // blk_tiles + 1) * blk_tiles * cpt
+            if not diag:
+                assert rrow_of.setdefault((int(tile), local), int(r_row)) == int(r_row)
             if diag:
                 assert tile * cpt <= c0 and c0 + cnt <= min((tile + 1) * cpt, chunks)
                 w += cnt * 48                      # one-sided body cost
@@ -44,24 +52,33 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
                 assert c0 >= (tile + 1) * cpt
                 w += cnt * 56                      # symmetric body cost
             cover[tile, c0:c0 + cnt] += 1
-        assert sorted(rrow_of.values()) == list(range(len(rrow_of)))
+        assert sorted(set(rrow_of.values())) == list(range(len(set(rrow_of.values()))))
         work.append(w)
     for tile in range(tiles):
         first = tile * cpt
         assert (cover[tile, first:] == 1).all(), tile      # own chunks (diagonal) and every later chunk: once
         assert (cover[tile, :first] == 0).all(), tile      # earlier chunks belong to the earlier tile's items
     if world > 1:
-        assert max(work) / (sum(work) / world) < 1.03       # snake dealing: within 3 % of the mean
+        assert max(work) / (sum(work) / world) < 1.02       # equal local blocks + equal cross runs
 
 
 def test_plan_fills_the_chip():
     for n, world, lo, hi in ((262144, 1, 6000, 10000), (262144, 8, 3000, 5000), (16384, 1, 1000, 1400)):
-        items, L = plan(n, world // 2, world)
+        items, nloc, L = plan(n, world // 2, world)
         assert lo <= len(items) <= hi, (n, world, len(items), L)
 
 
 def test_plan_rejects_bad_arguments():
     lib = nb.load()
     cnt = C.c_uint32()
-    assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, 0, C.byref(cnt), None) != 0
-    assert lib.nb_debug_sym_plan(1000, 256, 3, 2, None, 0, C.byref(cnt), None) != 0
+    assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, 0, C.byref(cnt), None, None) != 0
+    assert lib.nb_debug_sym_plan(1000, 256, 3, 2, None, 0, C.byref(cnt), None, None) != 0
+    assert lib.nb_debug_sym_plan(100000, 256, 0, 3, None, 0, C.byref(cnt), None, None) != 0   # blocks must be whole tiles
+
+
+def test_local_items_are_a_rank_independent_share():
+    """Every rank's local part (pairs inside its own block) is 1/world of its work at 8 ranks: what hides the all-gather."""
+    for world in (2, 4, 8):
+        items, nloc, L = plan(262144, world - 1, world)
+        loc = items[:nloc, 2].sum()
+        assert abs(loc / items[:, 2].sum() - 1.0 / world) < 0.03

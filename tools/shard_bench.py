@@ -25,6 +25,7 @@ def run(parts, rank):
             else:
                 for _ in range(k):
                     sim.step_begin(1e-3)
+                    sim.step_mid()
                     sim.step_finish()
         go(3); sim.wait()
         sim.profile(True)

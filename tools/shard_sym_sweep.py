@@ -17,7 +17,7 @@ for parts in (8, 4, 2, 1):
             def go(k):
                 if parts == 1: sim.advance(k, 1e-3)
                 else:
-                    for _ in range(k): sim.step_begin(1e-3); sim.step_finish()
+                    for _ in range(k): sim.step_begin(1e-3); sim.step_mid(); sim.step_finish()
             go(3); sim.wait(); sim.profile(True)
             t0 = time.perf_counter(); go(steps); sim.wait(); t = (time.perf_counter() - t0) / steps * 1e3
             ms, cnt = sim.profile_read()
