@@ -235,9 +235,13 @@ int   nb_shard_protocol(const nb_sim *s);
 /* Exchange for a host that drives SEVERAL sharded handles from one process (e.g. one per GPU of
  * the node, no RCCL): every handle's owned block of its CURRENT replica is copied into the CURRENT
  * replica of every other handle (peer copies; the handles may sit on different devices).  Call it
- * between nb_step_finish and the next nb_step_finish of NB_SHARD_ALLGATHER handles; it waits for
- * the handles' enqueued work and returns when the copies are done. */
+ * after nb_step_finish (before the next nb_step_finish / nb_step_mid); it waits for the handles'
+ * enqueued work and returns when the copies are done. */
 int   nb_exchange_positions(nb_sim *const *sims, int count);
+/* Same host, NB_SHARD_SYMMETRIC handles (all `count` ranks of the run, in rank order): the in-process
+ * reduce-scatter — every handle's nb_acc_buffer(1) receives the sum, in rank order, of all handles'
+ * partial accelerations of its block.  Call it between nb_step_mid and nb_step_finish. */
+int   nb_exchange_accelerations(nb_sim *const *sims, int count);
 void *nb_acc_buffer(nb_sim *s, int which);   /* 0: full-n partial, 1: owned block sum (NULL if unused) */
 int   nb_step_begin(nb_sim *s, float dt);
 int   nb_step_mid(nb_sim *s);      /* NB_SHARD_SYMMETRIC only (no-op otherwise): see below */

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "nb_stream": (C.c_void_p, [C.c_void_p]),
     "nb_shard_protocol": (C.c_int, [C.c_void_p]),
     "nb_exchange_positions": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "nb_exchange_accelerations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_acc_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),

@@ -1023,8 +1023,8 @@ extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
 {
     if (!sims || count < 1) { nb_set_error("nb_exchange_positions: no handles"); return NB_EINVAL; }
     for (int a = 0; a < count; ++a) {
-        if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz || sims[a]->sym_sharded) {
-            nb_set_error("nb_exchange_positions: handles must shard the same system with the all-gather protocol");
+        if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz) {
+            nb_set_error("nb_exchange_positions: handles must shard the same system");
             return NB_EINVAL;
         }
         if (bind(sims[a])) return NB_EHIP;
@@ -1040,6 +1040,37 @@ extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
             HIPCHK(hipMemcpyPeerAsync((char *)dst->pos[dst->cur] + own->i_begin * own->esz, dst->dev, src, own->dev,
                                       own->i_count * own->esz, dst->stream));
         }
+    }
+    for (int a = 0; a < count; ++a) {
+        if (bind(sims[a])) return NB_EHIP;
+        HIPCHK(hipStreamSynchronize(sims[a]->stream));
+    }
+    return NB_OK;
+}
+
+extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
+{
+    if (!sims || count < 1 || count > 64) { nb_set_error("nb_exchange_accelerations: 1..64 handles"); return NB_EINVAL; }
+    PartialPtrs src;
+    for (int a = 0; a < count; ++a) {
+        if (!sims[a] || !sims[a]->sym_sharded || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz ||
+            sims[a]->p.shard_world != count || sims[a]->p.shard_rank != a) {
+            nb_set_error("nb_exchange_accelerations: needs the `count` handles of one symmetric sharded run, in rank order");
+            return NB_EINVAL;
+        }
+        if (bind(sims[a])) return NB_EHIP;
+        HIPCHK(hipStreamSynchronize(sims[a]->stream));           // its partial accelerations are complete
+        src.p[a] = sims[a]->acc_full;
+    }
+    for (int o = 0; o < count; ++o) {
+        nb_sim *s = sims[o];
+        if (bind(s)) return NB_EHIP;
+        for (int r = 0; r < count; ++r)                          // peers' memory must be mapped on this device
+            if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+        const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+        if (s->fp64) sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (double2 *)s->acc_owned);
+        else         sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float2 *)s->acc_owned);
+        HIPCHK(hipGetLastError());
     }
     for (int a = 0; a < count; ++a) {
         if (bind(sims[a])) return NB_EHIP;

@@ -866,6 +866,27 @@ void integrate(const typename vec2_of<real>::type *__restrict__ pos_cur,
 }
 
 // ---------------------------------------------------------------------------
+// sum_partials — in-process reduce-scatter of the symmetric sharded protocol: dst[k] = sum over the
+// handles (in handle order) of their partial acceleration of particle first + k.  `src` holds the
+// handles' acc_full pointers (peer-accessible device memory); T is the element type.
+// ---------------------------------------------------------------------------
+struct PartialPtrs { const void *p[64]; };
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK)
+void sum_partials(PartialPtrs src, int count, uint32_t first, uint32_t cnt, T *__restrict__ dst)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= cnt) return;
+    T a = static_cast<const T *>(src.p[0])[first + k];
+    for (int r = 1; r < count; ++r) {
+        const T b = static_cast<const T *>(src.p[r])[first + k];
+        a.x += b.x; a.y += b.y;
+    }
+    dst[k] = a;
+}
+
+// ---------------------------------------------------------------------------
 // AoS (64-byte Body records, Body.hpp:6-13) <-> SoA
 // ---------------------------------------------------------------------------
 struct BodyRec { float4 q[4]; };  // pos|pad, vel|pad, acc|pad, mass radius pad pad

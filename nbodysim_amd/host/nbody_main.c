@@ -78,17 +78,24 @@ int main(int argc, char **argv)
         for (int r = 0; r < shards; ++r) {
             nb_params q = p;
             q.i_begin = (uint64_t)r * blk; q.i_count = blk; q.device = ndev > 0 ? r % ndev : 0;
+            q.shard_rank = r; q.shard_world = shards;   /* lets the library pick the symmetric protocol where it applies */
             h[r] = nb_create(bodies, n, &q);
             if (!h[r]) DIE("nb_create(shard %d): %s", r, nb_last_error());
         }
+        const int symmetric = nb_shard_protocol(h[0]) == NB_SHARD_SYMMETRIC;
         const double t0s = now_s();
         for (int s = 0; s < steps; ++s) {
             for (int r = 0; r < shards; ++r) CHECK(nb_step_begin(h[r], p.dt));
+            if (symmetric) {                              /* cross-block pairs, then the in-process reduce-scatter */
+                for (int r = 0; r < shards; ++r) CHECK(nb_step_mid(h[r]));
+                CHECK(nb_exchange_accelerations(h, shards));
+            }
             for (int r = 0; r < shards; ++r) CHECK(nb_step_finish(h[r]));
             CHECK(nb_exchange_positions(h, shards));
         }
         const double pers = (now_s() - t0s) / steps;
         for (int r = 0; r < shards; ++r) CHECK(nb_sync(h[r], bodies + (size_t)r * blk));
+        printf("protocol=%s ", symmetric ? "symmetric" : "allgather");
         printf("shards=%d on %d device(s): frame=%llu  %.3f ms/step  %.3e pair interactions/s\n", shards, ndev,
                (unsigned long long)nb_frame(h[0]), pers * 1e3, (double)n * (double)n / pers);
         printf("body[0]: pos=(%.6f, %.6f) vel=(%.6f, %.6f)\n", bodies[0].pos.x, bodies[0].pos.y, bodies[0].vel.x, bodies[0].vel.y);

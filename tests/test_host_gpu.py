@@ -72,17 +72,19 @@ def test_sync_into_page_locked_host_memory_is_identical():
             L.check("nb_host_unregister", lib.nb_host_unregister(pinned.ctypes.data))
 
 
-def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path):
+@pytest.mark.parametrize("n,protocol", [(8192, "allgather"), (65536, "symmetric")])
+def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, protocol):
     """`nbody_main -shards 4`: four sharded handles in one C process, exchanged with
-    nb_exchange_positions (the multi-GPU-without-RCCL host); same trajectory as one handle."""
+    nb_exchange_positions / nb_exchange_accelerations (the multi-GPU-without-RCCL host);
+    same trajectory as one handle, in both sharding protocols."""
     exe = ROOT / "build" / "nbody_main"
     dump = tmp_path / "sh.nbd"
-    r = subprocess.run([str(exe), "-n", "8192", "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)],
+    r = subprocess.run([str(exe), "-n", str(n), "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "shards=4" in r.stdout and "frame=6" in r.stdout
+    assert "shards=4" in r.stdout and "frame=6" in r.stdout and f"protocol={protocol}" in r.stdout
     back, frame, _ = nb.read_bodies(dump)
-    with nb.Simulation(nb.plummer_2d(8192, 42), eps=0.05) as sim:
+    with nb.Simulation(nb.plummer_2d(n, 42), eps=0.05) as sim:
         sim.advance(6, 1e-3)
         want = sim.sync()
     rel = np.max(np.linalg.norm(back["pos"].astype(np.float64) - want["pos"], axis=1) / np.linalg.norm(want["pos"].astype(np.float64), axis=1))
