@@ -553,3 +553,15 @@ def test_baseline_config3_size_one_million_bodies_single_gpu():
     f = (m * b["acc"].astype(np.float64)).sum(0)
     assert (np.abs(f) < 1e-5 * np.abs(m * b["acc"]).sum(0)).all()
     assert abs((k1 + u1 - k0 - u0) / (k0 + u0)) < 1e-5
+
+
+@pytest.mark.parametrize("n,kw", [(20000, {}), (20000, {"precision": "fp64"}), (5000, {}), (30000, {"dims": 3})])
+def test_results_are_bitwise_reproducible_run_to_run(n, kw):
+    """No atomics anywhere: slabs are summed in a fixed order, so two runs give identical bits."""
+    ic = nb.plummer_3d(n, 3) if kw.get("dims") == 3 else nb.plummer_2d(n, 3)
+    outs = []
+    for _ in range(2):
+        with nb.Simulation(ic, eps=0.02, **kw) as sim:
+            sim.advance(3, 1e-3)
+            outs.append(sim.sync().tobytes())
+    assert outs[0] == outs[1]
