@@ -6,16 +6,18 @@
 //   Quadtree::fast_inv_sqrt Quadtree.hpp:106-111    -> quake_rsqrt / RSQ_QUAKE
 //   Simulation::iterate()  Simulation.hpp:129-163   -> integrate_* kernels
 //
-// Design: the pair body is pure fp32 VALU work
-// (9 packed ops + 2 v_rsq_f32 per TWO pairs); there is no contraction to feed
-// MFMA.  Each lane owns 2*P i-particles held as P packed register pairs
-// (v_pk_add/fma/mul_f32 process the two halves at once, the j-particle is
-// broadcast through op_sel), j-particles stream through a double-buffered LDS
-// tile as float4 {x, y, m, m} read back by one broadcast ds_read_b128 per j per
-// wave.  The j range can be split into slices across workgroups (grid-level
-// j-split) so that small i-counts still fill 256 CUs; slices write partial sums
-// to slabs that the integrate kernel adds in a fixed order (deterministic, no
-// atomics).
+// Design: the pair body is pure VALU work (packed FP32 + v_rsq_f32); there is no
+// contraction over j with i-independent operands to feed MFMA.  Kernels in this file:
+//   force_sym_f32 / force_sym_f64   symmetric fast path: every unordered pair once (Newton's third
+//                                   law); stationary particles in registers, 64-particle travelling
+//                                   chunks rotated through the lanes with ds_bpermute_b32
+//   force_tiled_f32 / force_tiled_f64   one-sided: j-particles through a double-buffered LDS tile,
+//                                   one broadcast ds_read_b128 per j, 2P packed i-particles per lane,
+//                                   grid- and workgroup-level j-split
+//   force_seq_f32                   the reference's summation order, bit-exact parity mode
+//   sym_gather / integrate          fixed-order sums of the partial slabs + kick/drift (no atomics:
+//                                   results are reproducible run to run)
+//   pack/unpack/energy/sum_partials AoS <-> SoA, diagnostics, in-process reduce-scatter
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,7 +26,6 @@ namespace nbk {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int BLOCK = 256;  // 4 wave64 per workgroup
 constexpr int TJ = 256;     // j-particles per LDS tile (one per thread per stage)
