@@ -565,3 +565,29 @@ def test_results_are_bitwise_reproducible_run_to_run(n, kw):
             sim.advance(3, 1e-3)
             outs.append(sim.sync().tobytes())
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_symmetric_kernel_on_reference_scale_data(nbo, precision):
+    """Data shaped like the reference's demo (Simulation.hpp:347-603): a 1e9 central mass, 20 000 light bodies
+    out to 1e5, eps = 1 — nine orders of magnitude in mass, coordinates far from unit scale.  The symmetric
+    kernel (individual masses) must stay finite and follow the fp64 direct sum particle by particle."""
+    n = 20000
+    rng = np.random.default_rng(9)
+    b = nb.bodies_array(n)
+    rad, ang = 2000.0 + 1e5 * np.sqrt(rng.uniform(0, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    b["pos"] = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
+    b["mass"] = rng.uniform(0.1, 2.0, n).astype(np.float32)
+    b["pos"][0] = 0.0
+    b["mass"][0] = 1e9
+    with nb.Simulation(b, eps=1.0, precision=precision) as sim:
+        assert "symmetric=1" in sim.describe() and "uniform_mass=0" in sim.describe()
+        acc = sim.accelerations().astype(np.float64)
+    ax, ay = nbo.accel_f64(nbo.state_from_bodies(b, np.float64), 1.0)
+    ref = np.stack([ax, ay], 1)
+    assert np.isfinite(acc).all()
+    assert max_rel(acc[1:], ref[1:]) < (2e-5 if precision == "fp32" else 2e-7)     # float Body record limits fp64 to ~1e-7
+    # the central body feels the (nearly cancelling) pull of everything else: judged on its own force scale
+    m = b["mass"].astype(np.float64)
+    scale0 = np.sum(m[1:] / (rad[1:] ** 2))
+    assert np.linalg.norm(acc[0] - ref[0]) < 1e-5 * scale0
