@@ -298,6 +298,38 @@ static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t
             cum += cnt;
         }
     }
+    // Guided tail: workgroups are dispatched in item order and an item is a fixed amount of VALU work, so a
+    // launch ends with up to one item time of partly idle CUs (half of it on average: 3 % of a single-GPU step,
+    // 7 % of a rank's step at world = 8).  The end of each launch's work is cut into finer items
+    // (L/2, L/4, L/8 chunks from 85 %, 94 %, 98 % of the work on; profiles/r01_guided_tail_ab.log): -2 % step time.
+    // Splitting happens after the cross runs were assigned, so every rank still sees the same run boundaries.
+    if (!getenv("NB_SYM_NO_GUIDED_TAIL")) {
+        double tail_at[3] = {0.85, 0.94, 0.98};                                      // NB_SYM_TAIL="a,b,c" overrides (tools/guided_tail_ab.py)
+        if (const char *e = getenv("NB_SYM_TAIL")) (void)sscanf(e, "%lf,%lf,%lf", &tail_at[0], &tail_at[1], &tail_at[2]);
+        auto guided = [&](std::vector<SymItem> &list, std::vector<uint32_t> &rows_of) {
+            uint64_t total = 0, done = 0;
+            for (const auto &it : list) total += it.cnt;
+            std::vector<SymItem> out;
+            out.reserve(list.size() * 2);
+            for (const auto &it : list) {
+                const double f = total ? (double)done / (double)total : 0.0;
+                const uint32_t div = f < tail_at[0] ? 1u : f < tail_at[1] ? 2u : f < tail_at[2] ? 4u : 8u;
+                const uint32_t piece = (L + div - 1) / div;
+                done += it.cnt;
+                if (div == 1 || it.cnt <= piece) { out.push_back(it); continue; }
+                --rows_of[it.tile];
+                for (uint32_t c = 0; c < it.cnt; c += piece) {
+                    SymItem q = it;
+                    q.c0 = it.c0 + c; q.cnt = it.cnt - c < piece ? it.cnt - c : piece;
+                    out.push_back(q);
+                    ++rows_of[it.tile];
+                }
+            }
+            list.swap(out);
+        };
+        guided(local_items, local_rows_of);
+        guided(cross_items, cross_rows_of);
+    }
     // slab rows: a tile's stationary rows are contiguous (local items, then cross items); one travelling
     // row per (tile, part) with the particle range that part covers
     rowbase.assign(tiles + 1, 0);
