@@ -126,6 +126,9 @@ struct nb_sim {
     bool sym_sharded = false;
     void *acc_full = nullptr, *acc_owned = nullptr;     // reduce-scatter input (n) / output (i_count), (ax,ay) reals
     bool own_acc = true;
+    // the local items run on a side stream so that their tail and the head of the cross items share the chip
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // profiling
     bool prof = false;
@@ -396,6 +399,16 @@ static int plan_sym(nb_sim *s)
     HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_segs_dev, segs.data(), segs.size() * sizeof(SymSeg), hipMemcpyHostToDevice));
+    // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
+    // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
+    // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
+    // same trick costs 4 % — profiles/r01_aux_stream_ab.log — hence the bound).  NB_SYM_AUX_STREAM=0/1 forces it.
+    const char *auxenv = getenv("NB_SYM_AUX_STREAM");
+    if (s->sym_sharded && (auxenv ? atoi(auxenv) != 0 : s->sym_items_local <= 4u * (uint32_t)s->cus)) {
+        HIPCHK(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     if (s->sym_sharded) {
         if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
         else {
@@ -421,6 +434,9 @@ static void free_all(nb_sim *s)
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
     if (s->staging) (void)hipHostFree(s->staging);
+    if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -553,7 +569,7 @@ extern "C" int nb_upload(nb_sim *s, const nb_body *in)
 // ---------------------------------------------------------------------------
 // profiling events
 // ---------------------------------------------------------------------------
-static int prof_begin(nb_sim *s, std::pair<hipEvent_t, hipEvent_t> *pr)
+static int prof_begin(nb_sim *s, std::pair<hipEvent_t, hipEvent_t> *pr, hipStream_t st = nullptr)
 {
     if (s->ev_pool.empty()) {
         hipEvent_t a, b;
@@ -563,13 +579,13 @@ static int prof_begin(nb_sim *s, std::pair<hipEvent_t, hipEvent_t> *pr)
     }
     *pr = s->ev_pool.back();
     s->ev_pool.pop_back();
-    HIPCHK(hipEventRecord(pr->first, s->stream));
+    HIPCHK(hipEventRecord(pr->first, st ? st : s->stream));
     return NB_OK;
 }
 
-static int prof_end(nb_sim *s, const std::pair<hipEvent_t, hipEvent_t> &pr)
+static int prof_end(nb_sim *s, const std::pair<hipEvent_t, hipEvent_t> &pr, hipStream_t st = nullptr)
 {
-    HIPCHK(hipEventRecord(pr.second, s->stream));
+    HIPCHK(hipEventRecord(pr.second, st ? st : s->stream));
     s->ev_used.push_back(pr);
     return NB_OK;
 }
@@ -624,11 +640,12 @@ static void launch_tiled_f64(nb_sim *s, const ForceJob &j, double eps2)
 
 // Symmetric kernel over items [first, first + count) of this handle (HIP events around the launch
 // when profiling).
-static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count)
+static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream_t st = nullptr)
 {
     if (count == 0) return NB_OK;
+    if (!st) st = s->stream;
     std::pair<hipEvent_t, hipEvent_t> pr;
-    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+    if (s->prof && prof_begin(s, &pr, st)) return NB_EHIP;
     const uint32_t n = (uint32_t)s->n;
     const SymItem *items = s->sym_items_dev + first;
     const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
@@ -637,33 +654,33 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count)
         const float4 *pos = (const float4 *)s->pos[s->cur];
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
         if (s->uniform_mass) {
-            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, s->um_mass);
-            else       force_sym3_f32<RSQ_EXACT, true><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, s->um_mass);
+            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, s->um_mass);
+            else       force_sym3_f32<RSQ_EXACT, true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, s->um_mass);
         } else {
-            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, 1.0f);
-            else       force_sym3_f32<RSQ_EXACT, false><<<count, BLOCK, 0, s->stream>>>(pos, items, ss, sr, n, eps2, 1.0f);
+            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0f);
+            else       force_sym3_f32<RSQ_EXACT, false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0f);
         }
     } else if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
         const double *mass = (const double *)s->mass;
-        if (s->uniform_mass) force_sym_f64<true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
-        else                 force_sym_f64<false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
+        if (s->uniform_mass) force_sym_f64<true><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
+        else                 force_sym_f64<false><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
     } else {
         const float eps2 = s->p.eps * s->p.eps;
         const float2 *pos = (const float2 *)s->pos[s->cur];
         const float *mass = (const float *)s->mass;
         float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
         if (s->uniform_mass) {
-            if (quake) force_sym_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
-            else       force_sym_f32<RSQ_EXACT, true><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
+            if (quake) force_sym_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
+            else       force_sym_f32<RSQ_EXACT, true><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
         } else {
-            if (quake) force_sym_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
-            else       force_sym_f32<RSQ_EXACT, false><<<count, BLOCK, 0, s->stream>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
+            if (quake) force_sym_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
+            else       force_sym_f32<RSQ_EXACT, false><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
         }
     }
     HIPCHK(hipGetLastError());
-    if (s->prof && prof_end(s, pr)) return NB_EHIP;
+    if (s->prof && prof_end(s, pr, st)) return NB_EHIP;
     return NB_OK;
 }
 
@@ -815,7 +832,17 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     s->in_step = true;
-    if (s->sym_sharded) return launch_sym_items(s, 0, s->sym_items_local);   // pairs inside my own block: no remote data needed
+    if (s->sym_sharded) {
+        // pairs inside my own block: no remote data needed.  On the side stream (ordered after everything
+        // enqueued so far), so the cross items of nb_step_mid fill the CUs its last workgroups leave idle.
+        if (!s->aux) return launch_sym_items(s, 0, s->sym_items_local);
+        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+        const int rc = launch_sym_items(s, 0, s->sym_items_local, s->aux);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(s->ev_join, s->aux));
+        return NB_OK;
+    }
     // local j-block first: its positions are already resident, so this overlaps the exchange
     if (two_phase(s)) return launch_force(s, s->job_local);
     return NB_OK;
@@ -831,6 +858,7 @@ extern "C" int nb_step_mid(nb_sim *s)
     int rc = launch_sym_items(s, s->sym_items_local, s->sym_items - s->sym_items_local);   // cross-block pairs: need the gathered positions
     if (rc) return rc;
     s->mid_done = true;
+    if (s->aux) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));   // the local items' slabs
     return launch_sym_gather(s, false, 0.0);           // partial acceleration of every particle -> acc_full
 }
 
@@ -938,6 +966,7 @@ extern "C" int nb_wait(nb_sim *s)
 {
     if (!s) { nb_set_error("nb_wait: NULL handle"); return NB_EINVAL; }
     if (bind(s)) return NB_EHIP;
+    if (s->aux) HIPCHK(hipStreamSynchronize(s->aux));
     HIPCHK(hipStreamSynchronize(s->stream));
     return NB_OK;
 }
