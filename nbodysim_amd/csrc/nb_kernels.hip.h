@@ -578,11 +578,12 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 // Same items, tiles (2048 particles per workgroup) and slabs as force_sym_f32; a lane holds
 // 8 stationary particles as scalars (no packed fp64 exists), the travelling particle and its
 // accumulator are rotated as pairs of 32-bit halves (10 ds_bpermute_b32 per step, 8 with UM).
-// Body, both directions: 2 add + 2 fma + v_rsq_f64 (+5 refinement ops) + 2 mul + 4 fma
+// Body, both directions: 2 add + 2 fma + v_rsq_f64 + 6 ops (1/r^3 with its correction, rsqrt3_f64) + 4 fma
 // (+2 mul with individual masses) for 128 ordered interactions per wave.
 // ---------------------------------------------------------------------------
 constexpr int SYM_P64 = 8;    // stationary particles per lane: 64 * 8 = SYM_WT per wave
 __device__ __forceinline__ double rsqrt_f64(double x);
+__device__ __forceinline__ double rsqrt3_f64(double x);
 
 __device__ __forceinline__ double lane_rot64(double v, int addr)
 {
@@ -623,8 +624,7 @@ void sym_chunks_f64(const double2 *__restrict__ pos, const double *__restrict__ 
             for (int p = 0; p < SYM_P64; ++p) {
                 const double dx = xq - xi[p], dy = yq - yi[p];
                 const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
-                const double inv = rsqrt_f64(r2);
-                const double inv3 = inv * (inv * inv);
+                const double inv3 = rsqrt3_f64(r2);
                 if constexpr (UM) {
                     ax[p] = __builtin_fma(inv3, dx, ax[p]);
                     ay[p] = __builtin_fma(inv3, dy, ay[p]);
@@ -765,6 +765,19 @@ __device__ __forceinline__ double rsqrt_f64(double x)
     return __builtin_fma(y * e, c, y);
 }
 
+// x^(-3/2) in one go: with y = v_rsq_f64(x) and e = 1 - x y^2,  x^(-3/2) = y^3 (1 - e)^(-3/2)
+// = y^3 (1 + 3e/2 + 15e^2/8 + O(e^3)),  e ~ 1e-7: six operations after the v_rsq_f64 where
+// rsqrt_f64 followed by inv * inv * inv takes seven (the force kernels are VALU-bound: -5 %).
+__device__ __forceinline__ double rsqrt3_f64(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double y2 = y * y;
+    const double e = __builtin_fma(-x, y2, 1.0);
+    const double y3 = y2 * y;
+    const double c = __builtin_fma(e, 1.875, 1.5);
+    return __builtin_fma(y3 * e, c, y3);
+}
+
 template <int P, bool GUARD, int UNROLL>
 __global__ __launch_bounds__(BLOCK)
 void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__ mass,
@@ -813,15 +826,15 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const double dx = xj - xi[p], dy = yj - yi[p];
-                double r2, inv;
+                double r2, inv3;
                 if constexpr (GUARD) {
                     r2 = __builtin_fma(dy, dy, dx * dx);
-                    inv = r2 > 0.0 ? rsqrt_f64(r2) : 0.0;
+                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2) : 0.0;
                 } else {
                     r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
-                    inv = rsqrt_f64(r2);
+                    inv3 = rsqrt3_f64(r2);
                 }
-                const double s = (mj * inv) * (inv * inv);
+                const double s = mj * inv3;
                 ax[p] = __builtin_fma(s, dx, ax[p]);
                 ay[p] = __builtin_fma(s, dy, ay[p]);
             }
