@@ -266,6 +266,10 @@ int nb_describe(nb_sim *s, char *buf, size_t buflen);
 int nb_plummer_2d(nb_body *out, size_t n, uint32_t seed);
 /* The same sample without the projection: a true 3-D Plummer sphere (z in NB_Z) for dims = 3. */
 int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
+/* The bodies the reference's `Simulation()` starts from — Simulation.hpp:58-65 -> uniform_disc(n),
+ * :347-603 (n = 25 000 there): 1e9 central mass, a Lorenz-attractor trace of light bodies, sorted by
+ * radius, near-circular speeds; bit-identical to the compiled reference (tests/golden/default_ics.json). */
+int nb_default_ics(nb_body *out, size_t n);
 
 /* Host-only view of the symmetric kernel's work planner (no GPU needed; used by the CPU tests to check
  * that the items of all ranks cover every unordered (tile, chunk) pair exactly once and are balanced).

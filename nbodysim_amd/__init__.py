@@ -12,6 +12,7 @@ from ._lib import (  # noqa: F401
     NBodyError,
     bodies_array,
     load,
+    default_ics,
     plummer_2d,
     plummer_3d,
 )
@@ -24,6 +25,7 @@ __all__ = [
     "Simulation",
     "bodies_array",
     "load",
+    "default_ics",
     "plummer_2d",
     "plummer_3d",
     "read_bodies",

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "nb_default_ics": (C.c_int, [C.c_void_p, C.c_size_t]),
     "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
@@ -175,6 +176,13 @@ def plummer_3d(n: int, seed: int = 42) -> np.ndarray:
     """True 3-D Plummer sphere; view it with ``.view(BODY3_DTYPE)`` to reach z."""
     out = bodies_array(n)
     check("nb_plummer_3d", load().nb_plummer_3d(out.ctypes.data, n, seed))
+    return out
+
+
+def default_ics(n: int = 25000) -> np.ndarray:
+    """The bodies the reference's ``Simulation()`` starts from (Simulation.hpp:58-65, uniform_disc :347-603)."""
+    out = bodies_array(n)
+    check("nb_default_ics", load().nb_default_ics(out.ctypes.data, n))
     return out
 
 

@@ -1,10 +1,10 @@
 /* nb_host.c — host-only pieces of libnbody_hip.so (plain C, no HIP):
  * synthetic initial conditions and the build-defined dump format.
  *
- * The reference has neither a Plummer generator (its ICs are
- * Simulation::uniform_disc, Simulation.hpp:347-603, a Lorenz-attractor trace)
- * nor any file I/O; both are defined here and documented in
- * DESIGN.md as build-defined.
+ * The reference has neither a Plummer generator nor any file I/O;
+ * both are defined here and documented in DESIGN.md as build-defined.  Its own
+ * ICs (Simulation::uniform_disc, Simulation.hpp:347-603, a Lorenz-attractor
+ * trace) are restated in nb_default_ics.
  */
 #include "nbody.h"
 #include "nb_internal.h"
@@ -89,6 +89,154 @@ static int plummer(nb_body *out, size_t n, uint32_t seed, int dims)
         if (dims == 3) { NB_Z(out[i].pos) = (float)z; NB_Z(out[i].vel) = (float)w; }
         out[i].mass = mass;
         out[i].radius = 0.0f;
+    }
+    return NB_OK;
+}
+
+/* ---- the reference's own initial conditions ----------------------------------
+ * What `Simulation()` starts from (Simulation.hpp:58-65 -> uniform_disc(n), :347-603), restated:
+ * a 1e9 central mass; n-1 bodies laid along a forward-Euler trace of the Lorenz system
+ * (sigma 10, rho 28, beta 8/3, h = 0.01, from (0.1, 0, 0)) scaled by sqrt(n)*300.7/10 in x and y;
+ * masses from three uniform ranges picked with probabilities 0.825 : 0.125 : 0.025, radius =
+ * cbrt(mass); bodies sorted by distance from the centre; speeds set to sqrt(M(<r)/r) along the
+ * "unit" tangent that Vec2::normalize leaves behind — which divides x by the length TWICE
+ * (Vec2.hpp:226-235), so vx is ~1/r of what a circular orbit needs.  That is the workload the
+ * reference runs, so it is reproduced as is.  Arithmetic is fp32, one rounding per operation
+ * (built with -ffp-contract=off), random numbers are std::mt19937(0) through libstdc++'s
+ * uniform_real_distribution<float>: float(u32) / 2^32, stepped down when it rounds to 1.
+ * tests/golden/default_ics.json holds the sha256 of the reference's 25 000 bodies. */
+static float disc_u01(nb_mt *g)
+{
+    const float r = (float)mt_next(g) / 4294967296.0f;
+    return r >= 1.0f ? nextafterf(1.0f, 0.0f) : r;
+}
+
+/* Order of the reference's std::sort (Simulation.hpp:585-589; comparator: |pos|^2 ascending).  A few
+ * bodies tie in fp32 |pos|^2 and std::sort is not stable, so the order of the ties is whatever the
+ * algorithm of the reference's standard library leaves: libstdc++ (GCC 11.4, the toolchain the golden
+ * vectors were made with) — introsort: median-of-three quicksort down to runs of 16 (heapsort past depth
+ * 2*floor(log2 n), never reached here), then one insertion-sort pass.  Restated below on (key, index) pairs. */
+typedef struct { float key; uint32_t idx; } disc_key;
+
+static void disc_swap(disc_key *a, disc_key *b) { const disc_key t = *a; *a = *b; *b = t; }
+
+static void disc_sift_down(disc_key *v, size_t start, size_t len)
+{
+    /* plain binary max-heap sift (only reached if quicksort degenerates; ties may then order differently) */
+    for (size_t root = start, child; (child = 2 * root + 1) < len; root = child) {
+        if (child + 1 < len && v[child].key < v[child + 1].key) ++child;
+        if (!(v[root].key < v[child].key)) return;
+        disc_swap(&v[root], &v[child]);
+    }
+}
+
+static void disc_quick(disc_key *v, size_t first, size_t last, int depth)
+{
+    while (last - first > 16) {
+        if (depth-- == 0) {
+            disc_key *h = v + first;
+            const size_t len = last - first;
+            for (size_t i = len / 2; i-- > 0;) disc_sift_down(h, i, len);
+            for (size_t end = len; end-- > 1;) { disc_swap(&h[0], &h[end]); disc_sift_down(h, 0, end); }
+            return;
+        }
+        /* median of (first+1, middle, last-1) goes to `first` and is the pivot */
+        disc_key *r = &v[first], *a = &v[first + 1], *b = &v[first + (last - first) / 2], *c = &v[last - 1];
+        if (a->key < b->key) {
+            if (b->key < c->key) disc_swap(r, b); else if (a->key < c->key) disc_swap(r, c); else disc_swap(r, a);
+        } else if (a->key < c->key) disc_swap(r, a);
+        else if (b->key < c->key) disc_swap(r, c);
+        else disc_swap(r, b);
+        size_t lo = first + 1, hi = last;
+        for (;;) {
+            while (v[lo].key < v[first].key) ++lo;
+            --hi;
+            while (v[first].key < v[hi].key) --hi;
+            if (!(lo < hi)) break;
+            disc_swap(&v[lo], &v[hi]);
+            ++lo;
+        }
+        disc_quick(v, lo, last, depth);
+        last = lo;
+    }
+}
+
+static void disc_sort(disc_key *v, size_t n)
+{
+    if (n < 2) return;
+    int lg = 0;
+    for (size_t m = n; m > 1; m >>= 1) ++lg;
+    disc_quick(v, 0, n, 2 * lg);
+    const size_t guarded = n > 16 ? 16 : n;
+    for (size_t i = 1; i < n; ++i) {
+        const disc_key val = v[i];
+        size_t j = i;
+        if (i < guarded && val.key < v[0].key) { for (; j > 0; --j) v[j] = v[j - 1]; }
+        else { for (; val.key < v[j - 1].key; --j) v[j] = v[j - 1]; }      /* a smaller-or-equal key is known to sit to the left */
+        v[j] = val;
+    }
+}
+
+int nb_default_ics(nb_body *out, size_t n)
+{
+    if (!out && n) { nb_set_error("nb_default_ics: out is NULL"); return NB_EINVAL; }
+    if (n == 0) return NB_OK;
+    if (n > (1u << 24)) { nb_set_error("nb_default_ics: n = %zu too large", n); return NB_EINVAL; }
+    static const float lo[3] = {0.00005f, 1.2f, 5.0f}, hi[3] = {0.8f, 2.5f, 50.0f}, weight[3] = {0.825f, 0.125f, 0.025f};
+    float wsum = 0.0f, cum[3], run = 0.0f;
+    for (int k = 0; k < 3; ++k) wsum += weight[k];
+    for (int k = 0; k < 3; ++k) { const float w = weight[k] / wsum; run += w; cum[k] = run; }
+
+    nb_mt g;
+    mt_seed(&g, 0u);
+    const float outer = sqrtf((float)n) * 300.7f, scale = outer / 10.0f;
+    const float sigma = 10.0f, rho = 28.0f, beta = 8.0f / 3.0f, h = 0.01f;
+    float lx = 0.1f, ly = 0.0f, lz = 0.0f;
+
+    memset(out, 0, n * sizeof(nb_body));
+    out[0].mass = 1e9f;
+    out[0].radius = 200.0f;
+    for (size_t i = 1; i < n; ++i) {
+        const float dx = sigma * (ly - lx);
+        const float t0 = rho - lz, t1 = lx * t0, dy = t1 - ly;
+        const float t2 = lx * ly, t3 = beta * lz, dz = t2 - t3;
+        const float sx = dx * h, sy = dy * h, sz = dz * h;
+        lx += sx; ly += sy; lz += sz;
+        nb_body *b = &out[i];
+        b->pos.x = lx * scale;
+        b->pos.y = ly * scale;
+        float vx = -b->pos.y, vy = b->pos.x;
+        const float x2 = vx * vx, y2 = vy * vy, len = sqrtf(x2 + y2);
+        if (len > 0.0f) { vx /= len; vx /= len; vy /= len; }
+        b->vel.x = vx; b->vel.y = vy;
+        const float pick = disc_u01(&g);
+        int k = 0;
+        while (k < 3 && !(pick <= cum[k])) ++k;
+        if (k == 3) k = 0;
+        const float span = hi[k] - lo[k], mu = disc_u01(&g) * span;
+        b->mass = mu + lo[k];
+        b->radius = cbrtf(b->mass);
+    }
+    disc_key *order = (disc_key *)malloc(n * sizeof *order);
+    nb_body *tmp = (nb_body *)malloc(n * sizeof *tmp);
+    if (!order || !tmp) { free(order); free(tmp); nb_set_error("nb_default_ics: out of memory"); return NB_ENOMEM; }
+    for (size_t i = 0; i < n; ++i) {
+        const float x2 = out[i].pos.x * out[i].pos.x, y2 = out[i].pos.y * out[i].pos.y;
+        order[i].key = x2 + y2;
+        order[i].idx = (uint32_t)i;
+    }
+    disc_sort(order, n);
+    memcpy(tmp, out, n * sizeof *tmp);
+    for (size_t i = 0; i < n; ++i) out[i] = tmp[order[i].idx];
+    free(order); free(tmp);
+    float enclosed = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        nb_body *b = &out[i];
+        enclosed += b->mass;
+        if (b->pos.x == 0.0f && b->pos.y == 0.0f) continue;
+        const float x2 = b->pos.x * b->pos.x, y2 = b->pos.y * b->pos.y, r = sqrtf(x2 + y2);
+        const float v = sqrtf(enclosed / r);
+        b->vel.x *= v; b->vel.y *= v;
     }
     return NB_OK;
 }

@@ -10,9 +10,11 @@
 // A caller written against the reference — `simulation->step();` then copying
 // `simulation->bodies` (main.cpp:621-627) — compiles against this header
 // unchanged, with the O(N^2) force + kick/drift running on the MI355X.
-// Differences, all deliberate: the constructor takes the
-// initial bodies (the reference hard-codes uniform_disc(25000)); there is no
-// `quadtree` member (direct sum); collide() is not run (not gravity).
+// `Simulation()` starts, like the reference's, from uniform_disc(25000) with
+// epsilon = 1 and the velocity clamp + soft boundary of iterate() switched on;
+// a second constructor takes any initial bodies.  Differences, all deliberate
+// (DESIGN.md §boundary): there is no `quadtree` member (direct sum instead of
+// Barnes-Hut) and collide() is not run (not gravity).
 #pragma once
 #include <atomic>
 #include <cstddef>
@@ -45,6 +47,17 @@ public:
     float dt = 0.0f;            // unused by the reference too (Simulation.hpp:52)
     size_t frame = 0;
     std::vector<Body> bodies;
+
+    // Simulation.hpp:58-65 — the reference's own start (its n, epsilon, ICs; iterate()'s extras on).
+    Simulation() : Simulation(uniform_disc(25000), 1.0f, reference_params()) {}
+
+    // Simulation.hpp:347-603, bit-identical bodies (nb_default_ics).
+    static std::vector<Body> uniform_disc(size_t n)
+    {
+        std::vector<Body> b(n);
+        check(nb_default_ics(reinterpret_cast<nb_body *>(b.data()), n), "nb_default_ics");
+        return b;
+    }
 
     explicit Simulation(std::vector<Body> initial, float epsilon = 1.0f, const nb_params *overrides = nullptr)
         : bodies(std::move(initial))
@@ -83,6 +96,13 @@ public:
     nb_sim *handle() { return sim_; }
 
 private:
+    static const nb_params *reference_params()
+    {
+        static nb_params p;
+        nb_params_default(&p);
+        p.extras = NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY;     // Simulation.hpp:133-155
+        return &p;
+    }
     static void check(int rc, const char *what)
     {
         if (rc != NB_OK) throw std::runtime_error(std::string(what) + ": " + nb_last_error());

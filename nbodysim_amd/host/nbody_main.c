@@ -7,6 +7,8 @@
  *
  *   nbody_main [-n N] [-s steps] [-dt DT] [-eps EPS] [-seed S] [-fp64] [-quake]
  *              [-sequential] [-kdk] [-dump FILE] [-load FILE] [-sync-every K]
+ *              [-reference-ics]  the reference's own start: Simulation()'s 25 000-body disc (or -n N of it),
+ *                            eps = 1, dt = 0.01, velocity clamp + soft boundary (Simulation.hpp:58-65,116-163)
  *              [-shards P]   P sharded handles driven from this one process (device r mod #GPUs),
  *                            exchanged with nb_exchange_positions: multi-GPU without RCCL
  */
@@ -30,7 +32,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
     size_t n = 65536;
-    int steps = 20, sync_every = 0, shards = 1;
+    int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
     nb_params p;
@@ -38,7 +40,11 @@ int main(int argc, char **argv)
     p.eps = 0.01f;
     p.dt = 1e-3f;
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "-n") && i + 1 < argc) n = (size_t)strtoull(argv[++i], NULL, 10);
+        if (!strcmp(argv[i], "-n") && i + 1 < argc) { n = (size_t)strtoull(argv[++i], NULL, 10); n_given = 1; }
+        else if (!strcmp(argv[i], "-reference-ics")) {
+            reference_ics = 1;
+            p.eps = 1.0f; p.dt = 0.01f; p.extras = NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY;
+        }
         else if (!strcmp(argv[i], "-s") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-dt") && i + 1 < argc) p.dt = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "-eps") && i + 1 < argc) p.eps = (float)atof(argv[++i]);
@@ -55,6 +61,7 @@ int main(int argc, char **argv)
     }
 
     nb_body *bodies;
+    if (reference_ics && !n_given) n = 25000;
     if (load) {
         uint64_t frame;
         nb_params fp;
@@ -66,7 +73,8 @@ int main(int argc, char **argv)
     } else {
         bodies = (nb_body *)malloc(n * sizeof *bodies);
         if (!bodies) DIE("out of memory");
-        CHECK(nb_plummer_2d(bodies, n, seed));
+        if (reference_ics) CHECK(nb_default_ics(bodies, n));
+        else CHECK(nb_plummer_2d(bodies, n, seed));
     }
 
     if (shards > 1) {

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "Simulation.hpp"
@@ -26,6 +27,17 @@ static void simulation_thread(std::shared_ptr<Simulation> simulation, int frames
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "reference") {
+        // exactly what main.cpp does: default-constructed Simulation (25 000-body disc, eps = 1), dt = 0.01
+        auto simulation = std::make_shared<Simulation>();
+        simulation_thread(simulation, argc > 2 ? atoi(argv[2]) : 10);
+        double px = 0.0, py = 0.0;
+        for (const Body &b : SHARED_BODIES) { px += (double)b.mass * b.vel.x; py += (double)b.mass * b.vel.y; }
+        std::printf("frame=%zu bodies=%zu body1=(%.9g, %.9g) last=(%.9g, %.9g) p=(%.9g, %.9g)\n", simulation->frame,
+                    SHARED_BODIES.size(), SHARED_BODIES[1].pos.x, SHARED_BODIES[1].pos.y,
+                    SHARED_BODIES.back().pos.x, SHARED_BODIES.back().pos.y, px, py);
+        return 0;
+    }
     const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 4096;
     std::vector<Body> init(n);
     if (nb_plummer_2d(reinterpret_cast<nb_body *>(init.data()), n, 42) != NB_OK) return 1;

@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads, exports every symbol include/nbody.h declares,
 and its host-only entry points behave; compute entry points fail loudly without a GPU."""
 import ctypes as C
+import json
 import re
 import subprocess
 from pathlib import Path
@@ -183,3 +184,20 @@ def test_dump_header_records_dims(tmp_path):
     assert nb.load().nb_write_bodies(str(tmp_path / "d2").encode(), b3.ctypes.data, 100, 5, C.byref(p)) == 0
     back2, _, q2 = nb.read_bodies(tmp_path / "d2")
     assert q2.dims == 2 and not back2.view(nb.BODY3_DTYPE)["pos"][:, 2].any()    # planar dumps zero the padding
+
+
+def test_default_ics_are_bit_identical_to_the_reference_constructor(gold):
+    """nb_default_ics against the bodies the compiled reference's Simulation() holds (fixtures made by
+    oracle/make_golden.py from the real constructor): all 25 000 by sha256, the innermost 4096 value by value."""
+    import hashlib
+    b = nb.default_ics(25000)
+    flat = np.zeros((25000, 8), np.float32)
+    flat[:, 0:2], flat[:, 2:4], flat[:, 4:6], flat[:, 6], flat[:, 7] = b["pos"], b["vel"], b["acc"], b["mass"], b["radius"]
+    want = json.loads((ROOT / "tests" / "golden" / "default_ics.json").read_text())
+    assert hashlib.sha256(flat.tobytes()).hexdigest() == want["sha256_float32_le"]
+    assert np.array_equal(flat[:4096].view(np.uint32), gold["default_ics_first4096"].view(np.uint32))
+    assert [float(v) for v in flat[1]] == want["body1"] and [float(v) for v in flat[-1]] == want["body_last"]
+    assert not b.view(np.uint8).reshape(25000, 64)[:, [8, 15, 24, 31, 40, 47, 56, 63]].any()     # padding zeroed
+    one = nb.default_ics(1)
+    assert one["mass"][0] == 1e9 and one["radius"][0] == 200.0 and not one["pos"].any()
+    assert nb.default_ics(0).shape == (0,)

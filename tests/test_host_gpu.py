@@ -89,3 +89,18 @@ def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, prot
         want = sim.sync()
     rel = np.max(np.linalg.norm(back["pos"].astype(np.float64) - want["pos"], axis=1) / np.linalg.norm(want["pos"].astype(np.float64), axis=1))
     assert frame == 6 and rel < 2e-6
+
+
+def test_cxx_default_constructed_simulation_is_the_reference_start():
+    """`std::make_shared<Simulation>()` as in main.cpp:657: 25 000-body disc, eps = 1, dt = SIMULATION_DT = 0.01."""
+    exe = ROOT / "build" / "sim_thread_example"
+    r = subprocess.run([str(exe), "reference", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"frame=(\d+) bodies=(\d+) body1=\(([-0-9.e+]+), ([-0-9.e+]+)\) last=\(([-0-9.e+]+), ([-0-9.e+]+)\)", r.stdout)
+    assert m and int(m.group(1)) == 3 and int(m.group(2)) == 25000, r.stdout
+    with nb.Simulation(nb.default_ics(), eps=1.0, extras=3) as sim:
+        sim.advance(3, 0.01)
+        b = sim.sync()
+    got = np.array([float(m.group(k)) for k in (3, 4, 5, 6)])
+    want = np.concatenate([b["pos"][1], b["pos"][-1]]).astype(np.float64)
+    assert np.allclose(got, want, rtol=1e-6, atol=0)

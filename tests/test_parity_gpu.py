@@ -591,3 +591,36 @@ def test_symmetric_kernel_on_reference_scale_data(nbo, precision):
     m = b["mass"].astype(np.float64)
     scale0 = np.sum(m[1:] / (rad[1:] ** 2))
     assert np.linalg.norm(acc[0] - ref[0]) < 1e-5 * scale0
+
+
+def test_reference_full_default_start_through_the_gpu_path(nbo):
+    """What `Simulation()` runs in the reference, all of it: nb_default_ics (bit-identical to uniform_disc(25000),
+    tests/test_abi.py), eps = 1, dt = 0.01, velocity clamp and soft boundary on.  One body in seven starts
+    beyond the 8e4 soft boundary, whose exp() differs in the last bit between libm and the GPU, so after the
+    first force evaluation (bit-exact) the parity mode is held to 1e-6 and the fast mode to 1e-5."""
+    ic = nb.default_ics()
+    flat = flat_from_bodies(ic)
+    assert ic.shape[0] == 25000 and flat[0, 6] == 1e9
+    far = np.hypot(flat[:, 0], flat[:, 1]) > 8e4
+    assert 0.1 < far.mean() < 0.6
+    # reference arithmetic, reference order
+    with nb.Simulation(ic, eps=1.0, rsqrt="quake", order="sequential", extras=3) as sim:
+        sim.advance(1, 0.01)
+        one = flat_from_bodies(sim.sync())
+        sim.advance(4, 0.01)
+        five = flat_from_bodies(sim.sync())
+    st = nbo.step_f32(nbo.state_from_flat(flat), 1.0, 0.01, 1, nbo.RSQRT_QUAKE, 3)
+    want1 = nbo.state_to_flat(st).copy()
+    want5 = nbo.state_to_flat(nbo.step_f32(st, 1.0, 0.01, 4, nbo.RSQRT_QUAKE, 3))
+    assert np.array_equal(bits(one[:, 4:6]), bits(want1[:, 4:6]))                       # accelerations: every body
+    assert np.array_equal(bits(one[~far, 0:4]), bits(want1[~far, 0:4]))                 # inside the boundary: bit-exact step
+    assert max_rel(one[far, 0:2], want1[far, 0:2]) < 1e-6 and max_rel(one[far, 2:4], want1[far, 2:4]) < 1e-6
+    assert max_rel(five[:, 0:2], want5[:, 0:2]) < 1e-6 and max_rel(five[1:, 2:4], want5[1:, 2:4]) < 1e-5
+    assert (np.hypot(five[:, 2], five[:, 3]) <= 1000.0 * (1 + 1e-6)).all()              # the clamp held
+    # fast mode: symmetric kernel with individual masses against the exact-rsqrt restatement
+    with nb.Simulation(ic, eps=1.0, extras=3) as sim:
+        assert "symmetric=1" in sim.describe() and "uniform_mass=0" in sim.describe()
+        sim.advance(5, 0.01)
+        fast = flat_from_bodies(sim.sync())
+    ex = nbo.state_to_flat(nbo.step_f32(nbo.state_from_flat(flat), 1.0, 0.01, 5, nbo.RSQRT_EXACT, 3))
+    assert max_rel(fast[:, 0:2], ex[:, 0:2]) < 1e-5 and max_rel(fast[1:, 2:4], ex[1:, 2:4]) < 1e-5
