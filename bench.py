@@ -93,6 +93,8 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     args = ap.parse_args()
 
+    # RCCL shares device buffers between the ranks of a node through dmabuf IPC on this driver stack
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.protocol == "allgather":
         os.environ["NB_NO_SYMMETRY"] = "1"      # read by the library at nb_create: one-sided kernels, all-gather protocol
 
