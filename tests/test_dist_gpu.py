@@ -93,3 +93,47 @@ def test_distributed_simulation_matches_single_handle(tmp_path, world, backend, 
         e = np.load(tmp_path / f"energy_{r}.npy")   # all-reduced: every rank holds the total
         assert abs(e[0] + e[1] - (e_ref[0] + e_ref[1])) < 1e-9 * abs(e_ref[0] + e_ref[1])
         assert abs(e[2] + e[3] - (e_ref[2] + e_ref[3])) < 1e-6 * abs(e_ref[2] + e_ref[3])
+
+
+def _rccl_calls_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    from nbodysim_amd.dist import ShardPlan
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        n = 32768
+        plan = ShardPlan(n, world, rank)
+        stream = torch.cuda.Stream()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for dtype in (torch.float32, torch.float64):
+            full = torch.randn((n, 2), dtype=dtype, device="cuda", generator=g)
+            acc_full = torch.randn((n, 2), dtype=dtype, device="cuda", generator=g)
+            acc_owned = torch.zeros((plan.i_count, 2), dtype=dtype, device="cuda")
+            before = full.clone()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):        # the calls DistributedSimulation.step issues, on a side stream
+                dist.reduce_scatter_tensor(acc_owned, acc_full, op=dist.ReduceOp.SUM)
+                # what exchange_positions does for world > 1 — in place: the input is a slice of the output
+                work = dist.all_gather_into_tensor(full, full[plan.i_begin:plan.i_end], async_op=True)
+                work.wait()
+            stream.synchronize()
+            assert torch.equal(acc_owned, acc_full[plan.i_begin:plan.i_end])   # world 1: the sum is the input
+            assert torch.equal(full, before)
+        Path(out_dir, f"rccl_ok_{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_accepts_the_buffers_and_calls_of_the_symmetric_protocol(tmp_path):
+    """reduce_scatter_tensor on (n,2) -> (n/P,2) tensors and the in-place asynchronous all_gather_into_tensor, through
+    RCCL itself (one rank: all a one-GPU box allows) — argument checks, stream semantics, fp32 and fp64."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_calls_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "rccl_ok_0").exists()
