@@ -186,7 +186,7 @@ def main() -> None:
             except Exception:
                 traffic = None
         line = {
-            "metric": "particle-pair interactions/sec at N=262,144 (direct O(N^2) softened gravity + kick/drift step)",
+            "metric": f"particle-pair interactions/sec at N={n:,} (direct O(N^2) softened gravity + kick/drift step)",
             "value": value,
             "unit": "pair interactions/s",
             "n_gpus": world,
