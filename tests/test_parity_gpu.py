@@ -624,3 +624,28 @@ def test_reference_full_default_start_through_the_gpu_path(nbo):
         fast = flat_from_bodies(sim.sync())
     ex = nbo.state_to_flat(nbo.step_f32(nbo.state_from_flat(flat), 1.0, 0.01, 5, nbo.RSQRT_EXACT, 3))
     assert max_rel(fast[:, 0:2], ex[:, 0:2]) < 1e-5 and max_rel(fast[1:, 2:4], ex[1:, 2:4]) < 1e-5
+
+
+def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
+    """Index arithmetic far beyond the BASELINE sizes: a handle that owns the LAST 4096 + 77 particles of
+    n = 4 194 381 (ragged: not a multiple of any tile) computes their accelerations from all n bodies; the CPU
+    fp64 direct sum over the same i-range (1.7e10 pairs) is the check.  Also the symmetric path's 8 GiB slab cap:
+    a whole-system handle of this size must choose the one-sided kernel."""
+    n, own = (1 << 22) + 77, 4096 + 77
+    ic = nb.plummer_2d(n, 3)
+    with nb.Simulation(ic, eps=0.01, i_begin=n - own, i_count=own) as sim:
+        assert sim.shard_protocol == L.NB_SHARD_ALLGATHER
+        sim.step_begin(1e-3)
+        sim.step_finish()
+        got = sim.sync()
+    assert got.shape[0] == own
+    acc = got["acc"].astype(np.float64)
+    ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), float(np.float32(0.01)), n - own, n)
+    ref = np.stack([ax[n - own:], ay[n - own:]], 1)
+    assert np.max(np.abs(acc - ref)) < 1e-5 * np.max(np.abs(ref))
+    # kick + drift of the owned block with those accelerations
+    v1 = ic["vel"][n - own:].astype(np.float64) + ref * 1e-3
+    x1 = ic["pos"][n - own:].astype(np.float64) + v1 * 1e-3
+    assert max_rel(got["vel"], v1) < 1e-5 and max_rel(got["pos"], x1) < 1e-6
+    with nb.Simulation(ic, eps=0.01) as sim:
+        assert "symmetric=0" in sim.describe()          # 2049 travelling rows x n x 8 B = 64 GiB > cap
