@@ -130,6 +130,12 @@ def main() -> None:
             dist.init_process_group("gloo")
         sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank)
         inner = sim.sim
+        # bring the communicator up (channels, RCCL kernels) before anything is timed, whatever --warmup is
+        scratch = torch.zeros((world * 64, 2), dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(scratch, scratch[rank * 64:(rank + 1) * 64])
+        if args.backend == "nccl":
+            dist.reduce_scatter_tensor(scratch[:64].clone(), scratch, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
         advance, wait = sim.advance, sim.wait
 
         def barrier():
