@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -268,7 +269,18 @@ static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t
         cross_total += chunks - be;
     }
     const uint32_t target = (world > 1 ? 16u : 32u) * cus;                        // workgroups wanted (profiles/r01_*sweep.log)
-    uint32_t L = forced_L ? forced_L : (uint32_t)((local + cross_total / world + target - 1) / target);
+    // Chunks per item.  Large systems: as many items as fill the chip `target` workgroups deep.  Small ones
+    // (fewer chunk-units than that): one chunk per item would be the finest grain, but every item costs a
+    // 16-KiB slab row that sym_gather re-reads and a prologue, while coarse items cost tail — the optimum
+    // sits near items ~ 20 sqrt(units) at 256 CUs (profiles/r01_force_sym_small_n_sweep.log: L = 2 at
+    // N = 16 384, 3 at 25 000-32 768, 4-6 at 65 536, -5 ... -10 % step time against L = 1).
+    const uint64_t units = local + cross_total / world;
+    uint32_t L = forced_L;
+    if (!L) {
+        const uint32_t fill = (uint32_t)((units + target - 1) / target);
+        const uint32_t grain = (uint32_t)(sqrt((double)units) * 256.0 / (20.0 * (double)cus) + 0.5);
+        L = fill > grain ? fill : grain;
+    }
     if (L < 1) L = 1;
 
     // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)

@@ -63,7 +63,7 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
 
 
 def test_plan_fills_the_chip():
-    for n, world, lo, hi in ((262144, 1, 6000, 14000), (262144, 8, 3000, 6000), (16384, 1, 1000, 1400)):
+    for n, world, lo, hi in ((262144, 1, 6000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 1400)):
         items, nloc, L = plan(n, world // 2, world)
         assert lo <= len(items) <= hi, (n, world, len(items), L)
 
