@@ -229,7 +229,10 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *                        flight); host waits for the all-gather; nb_step_mid = its share of the cross-block
  *                        pairs, then the partial acceleration of ALL particles into nb_acc_buffer(0); host
  *                        reduce-scatters it (sum) into nb_acc_buffer(1); finish = kick, drift of the owned
- *                        block; host starts the all-gather of the new positions. */
+ *                        block; host starts the all-gather of the new positions.  (From 8 ranks on,
+ *                        nb_step_mid also starts a held-back share of the own-block pairs on a side stream;
+ *                        it runs while the reduce-scatter is in flight and nb_step_finish adds its result to
+ *                        nb_acc_buffer(1) — nothing changes for the host.) */
 enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2 };
 int   nb_shard_protocol(const nb_sim *s);
 /* Exchange for a host that drives SEVERAL sharded handles from one process (e.g. one per GPU of

@@ -118,9 +118,10 @@ struct nb_sim {
 
     // symmetric path (force_sym_f32): work items and its two slab sets
     bool sym = false;
-    uint32_t sym_items = 0, sym_items_local = 0, sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_nsegs = 0;
+    uint32_t sym_items = 0, sym_items_local = 0, sym_items_cross = 0, sym_items_late = 0;   // [local | cross | late]
+    uint32_t sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_nsegs = 0, sym_nsegs_late = 0;
     SymItem *sym_items_dev = nullptr;          // local items first, then the cross-block items
-    uint32_t *sym_rowbase_dev = nullptr;
+    uint32_t *sym_rowbase_dev = nullptr;       // 3 x tiles: first row / first late row / end row of every tile
     SymSeg *sym_segs_dev = nullptr;
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
@@ -128,8 +129,10 @@ struct nb_sim {
     void *acc_full = nullptr, *acc_owned = nullptr;     // reduce-scatter input (n) / output (i_count), (ax,ay) reals
     bool own_acc = true;
     // the local items run on a side stream so that their tail and the head of the cross items share the chip
+    // and the late items run there while the reduce-scatter is in flight
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_local = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_late = nullptr;
 
     // profiling
     bool prof = false;
@@ -251,9 +254,21 @@ static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
 // Outputs: the items of `rank` (n_local local ones first), the first slab_s row of every tile (rowbase,
 // tiles + 1 entries; a tile's rows are its local items then its cross items) and the slab_r row segments
 // (row, particle range) the rank's items write.  Returns the chunks per item, L.
-static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, uint32_t forced_L,
-                               std::vector<SymItem> &items, uint32_t &n_local, std::vector<uint32_t> &rowbase,
-                               std::vector<SymSeg> &segs)
+//   LATE items   (world > 1) a small tail of the local items, held back until the cross items are done: they
+//                touch only the rank's own block, so they can run while the reduce-scatter of the partial
+//                accelerations is in flight, and are folded in by the integrate step.
+// Items come out as [local | cross | late] (SymItem::pad0 = 0 / 1 / 2); a tile's stationary rows are
+// [rowbase[g], rowmid[g]) for local + cross and [rowmid[g], rowbase[g+1]) for late; segs holds the
+// nsegs_main segments of local + cross first, then the late ones.
+struct SymPlan {
+    std::vector<SymItem> items;
+    uint32_t n_local = 0, n_cross = 0, n_late = 0, nsegs_main = 0, L = 0;
+    std::vector<uint32_t> rowbase, rowmid;
+    std::vector<SymSeg> segs;
+};
+
+static void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, uint32_t forced_L,
+                           uint32_t late_units, SymPlan &pl, uint32_t late_chunks = 2)
 {
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
     const uint32_t tpb = world > 1 ? (n / world) / SYM_SB : tiles;                 // tiles per block
@@ -284,9 +299,8 @@ static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t
     if (L < 1) L = 1;
 
     // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
-    std::vector<SymItem> local_items, cross_items;
-    std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0);
-    std::vector<uint32_t> cross_lo(tiles, 0xffffffffu), cross_hi(tiles, 0);
+    std::vector<SymItem> local_items, cross_items, late_items;
+    std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0), late_rows_of(tiles, 0);
     uint64_t cum = 0;
     for (uint32_t I = 0; I < tiles; ++I) {
         const uint32_t be = block_end_chunk(I);
@@ -307,11 +321,29 @@ static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t
             if (owner == rank) {
                 cross_items.push_back(SymItem{I, c, cnt, 0u, 0u, 0u, 0u, 0u});
                 ++cross_rows_of[I];
-                if (c < cross_lo[I]) cross_lo[I] = c;
-                if (c + cnt > cross_hi[I]) cross_hi[I] = c + cnt;
             }
             cum += cnt;
         }
+    }
+    // Late items: whole items off the end of the local list, at most late_units chunk-units and at most half
+    // of the local work, re-cut into 2-chunk items (1 in fp64; they run alone on the chip: fine grain, short tail).
+    if (world > 1 && late_units > 0) {
+        const uint64_t budget = late_units < local / 2 ? late_units : local / 2;
+        uint64_t taken = 0;
+        std::vector<SymItem> held;
+        while (!local_items.empty() && taken + local_items.back().cnt <= budget) {
+            taken += local_items.back().cnt;
+            --local_rows_of[local_items.back().tile];
+            held.push_back(local_items.back());
+            local_items.pop_back();
+        }
+        for (auto it = held.rbegin(); it != held.rend(); ++it)
+            for (uint32_t c = 0; c < it->cnt; c += late_chunks) {
+                SymItem q = *it;
+                q.c0 = it->c0 + c; q.cnt = it->cnt - c < late_chunks ? it->cnt - c : late_chunks;
+                late_items.push_back(q);
+                ++late_rows_of[q.tile];
+            }
     }
     // Guided tail: workgroups are dispatched in item order and an item is a fixed amount of VALU work, so a
     // launch ends with up to one item time of partly idle CUs (half of it on average: 3 % of a single-GPU step,
@@ -345,45 +377,75 @@ static uint32_t build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t
         guided(local_items, local_rows_of);
         guided(cross_items, cross_rows_of);
     }
-    // slab rows: a tile's stationary rows are contiguous (local items, then cross items); one travelling
-    // row per (tile, part) with the particle range that part covers
-    rowbase.assign(tiles + 1, 0);
-    segs.clear();
-    std::vector<uint32_t> next_local(tiles), next_cross(tiles), seg_local(tiles, 0), seg_cross(tiles, 0);
+    // slab rows: a tile's stationary rows are contiguous (local, cross, then late items); one travelling
+    // row per (tile, group) with the particle range the group's symmetric items cover
+    auto span_of = [&](const std::vector<SymItem> &list, std::vector<uint32_t> &lo, std::vector<uint32_t> &hi) {
+        lo.assign(tiles, 0xffffffffu); hi.assign(tiles, 0);
+        for (const auto &it : list) {
+            if (it.diag) continue;
+            if (it.c0 < lo[it.tile]) lo[it.tile] = it.c0;
+            if (it.c0 + it.cnt > hi[it.tile]) hi[it.tile] = it.c0 + it.cnt;
+        }
+    };
+    std::vector<uint32_t> llo, lhi, clo, chi, tlo, thi;
+    span_of(local_items, llo, lhi); span_of(cross_items, clo, chi); span_of(late_items, tlo, thi);
+    pl.rowbase.assign(tiles + 1, 0);
+    pl.rowmid.assign(tiles, 0);
+    pl.segs.clear();
+    std::vector<uint32_t> next_local(tiles), next_cross(tiles), next_late(tiles), seg_local(tiles, 0), seg_cross(tiles, 0), seg_late(tiles, 0);
     uint32_t row = 0, rrow = 0;
+    auto up = [](uint32_t v, uint32_t cap) { return v < cap ? v : cap; };
     for (uint32_t I = 0; I < tiles; ++I) {
-        rowbase[I] = row;
+        pl.rowbase[I] = row;
         next_local[I] = row; row += local_rows_of[I];
         next_cross[I] = row; row += cross_rows_of[I];
-        const uint32_t be = block_end_chunk(I), dend = (I + 1) * cpt < chunks ? (I + 1) * cpt : chunks;
-        if ((I / tpb == rank || world == 1) && be > dend) { seg_local[I] = rrow; segs.push_back(SymSeg{rrow++, dend * SYM_CH, be * SYM_CH, I}); }
-        if (cross_rows_of[I]) { seg_cross[I] = rrow; segs.push_back(SymSeg{rrow++, cross_lo[I] * SYM_CH, cross_hi[I] * SYM_CH, I}); }
+        pl.rowmid[I] = row;
+        next_late[I] = row; row += late_rows_of[I];
+        if (lhi[I] > llo[I]) { seg_local[I] = rrow; pl.segs.push_back(SymSeg{rrow++, llo[I] * SYM_CH, up(lhi[I] * SYM_CH, n), I}); }
+        if (chi[I] > clo[I]) { seg_cross[I] = rrow; pl.segs.push_back(SymSeg{rrow++, clo[I] * SYM_CH, up(chi[I] * SYM_CH, n), I}); }
     }
-    rowbase[tiles] = row;
-    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_row = seg_local[it.tile]; }
-    for (auto &it : cross_items) { it.s_row = next_cross[it.tile]++; it.r_row = seg_cross[it.tile]; }
-    n_local = (uint32_t)local_items.size();
-    items = std::move(local_items);
-    items.insert(items.end(), cross_items.begin(), cross_items.end());
-    return L;
+    pl.rowbase[tiles] = row;
+    pl.nsegs_main = (uint32_t)pl.segs.size();
+    for (uint32_t I = 0; I < tiles; ++I)
+        if (thi[I] > tlo[I]) { seg_late[I] = rrow; pl.segs.push_back(SymSeg{rrow++, tlo[I] * SYM_CH, up(thi[I] * SYM_CH, n), I}); }
+    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_row = seg_local[it.tile]; it.pad0 = 0u; }
+    for (auto &it : cross_items) { it.s_row = next_cross[it.tile]++; it.r_row = seg_cross[it.tile]; it.pad0 = 1u; }
+    for (auto &it : late_items)  { it.s_row = next_late[it.tile]++;  it.r_row = seg_late[it.tile];  it.pad0 = 2u; }
+    pl.n_local = (uint32_t)local_items.size();
+    pl.n_cross = (uint32_t)cross_items.size();
+    pl.n_late = (uint32_t)late_items.size();
+    pl.items = std::move(local_items);
+    pl.items.insert(pl.items.end(), cross_items.begin(), cross_items.end());
+    pl.items.insert(pl.items.end(), late_items.begin(), late_items.end());
+    pl.L = L;
 }
 
-// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag, 0, 0);
-// the first *n_local of them are the rank's local items.
+// Chunk-units of local work a rank holds back to run beside the reduce-scatter: 40 us of whole-chip work at the
+// measured 35 units/us (fp32) or 14 (fp64) of 256 CUs.  Alone on the chip those items take 50-60 us and the
+// hand-over between the streams ~15 us, so the split pays when the collective is exposed for longer than that
+// share of a step: from 8 ranks on (a rank's step at N = 262 144 is ~1 ms there; at 2-4 ranks it measured
+// neutral to -2 %, profiles/r01_late_items_ab.log).  NB_SYM_LATE_US=<us> forces it for any world size, 0 disables.
+static uint32_t late_units_for(bool fp64, int cus, uint32_t world)
+{
+    const char *e = getenv("NB_SYM_LATE_US");
+    const double us = e ? atof(e) : (world >= 8 ? 40.0 : 0.0);
+    if (!(us > 0.0)) return 0;
+    return (uint32_t)(us * (fp64 ? 14.0 : 35.0) * (double)cus / 256.0);
+}
+
+// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag,
+// group (0 local, 1 cross, 2 late), 0); the first *n_local of them are the rank's (early) local items.
 extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
                                  uint32_t *n_items, uint32_t *n_local, uint32_t *chunks_per_item)
 {
     if (n == 0 || n > 0x7fffff00u || cus < 1 || world < 1 || rank < 0 || rank >= world ||
         (world > 1 && (n % ((size_t)world * SYM_SB)) != 0)) { nb_set_error("nb_debug_sym_plan: bad arguments"); return NB_EINVAL; }
-    std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase;
-    std::vector<SymSeg> segs;
-    uint32_t nl = 0;
-    const uint32_t L = build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, items, nl, rowbase, segs);
-    if (n_items) *n_items = (uint32_t)items.size();
-    if (n_local) *n_local = nl;
-    if (chunks_per_item) *chunks_per_item = L;
-    if (items_out) memcpy(items_out, items.data(), (items.size() < cap ? items.size() : cap) * sizeof(SymItem));
+    SymPlan pl;
+    build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, late_units_for(false, cus, (uint32_t)world), pl);
+    if (n_items) *n_items = (uint32_t)pl.items.size();
+    if (n_local) *n_local = pl.n_local;
+    if (chunks_per_item) *chunks_per_item = pl.L;
+    if (items_out) memcpy(items_out, pl.items.data(), (pl.items.size() < cap ? pl.items.size() : cap) * sizeof(SymItem));
     return NB_OK;
 }
 
@@ -394,32 +456,35 @@ static int plan_sym(nb_sim *s)
     const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
     const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB;
     const char *envl = getenv("NB_SYM_L");
-    std::vector<SymItem> items;
-    std::vector<uint32_t> rowbase;
-    std::vector<SymSeg> segs;
-    uint32_t n_local = 0;
-    const uint32_t L = build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u,
-                                      items, n_local, rowbase, segs);
-    const uint32_t row = rowbase[tiles], rrow = (uint32_t)segs.size();
-    s->sym_items_local = n_local; s->sym_nsegs = rrow;
-    s->sym_items = (uint32_t)items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = L;
-    HIPCHK(hipMalloc((void **)&s->sym_items_dev, items.size() * sizeof(SymItem)));
-    HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, rowbase.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&s->sym_segs_dev, (segs.size() ? segs.size() : 1) * sizeof(SymSeg)));
+    SymPlan pl;
+    build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u,
+                   s->sym_sharded ? late_units_for(s->fp64, s->cus, world) : 0u, pl, s->fp64 ? 1u : 2u);
+    const uint32_t row = pl.rowbase[tiles], rrow = (uint32_t)pl.segs.size();
+    s->sym_items_local = pl.n_local; s->sym_items_cross = pl.n_cross; s->sym_items_late = pl.n_late;
+    s->sym_nsegs = pl.nsegs_main; s->sym_nsegs_late = rrow - pl.nsegs_main;
+    s->sym_items = (uint32_t)pl.items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = pl.L;
+    // row bounds for the gathers: [lo | mid | hi] = rowbase[0..tiles), rowmid[0..tiles), rowbase[1..tiles]
+    std::vector<uint32_t> bounds(3 * (size_t)tiles);
+    for (uint32_t g = 0; g < tiles; ++g) { bounds[g] = pl.rowbase[g]; bounds[tiles + g] = pl.rowmid[g]; bounds[2 * (size_t)tiles + g] = pl.rowbase[g + 1]; }
+    HIPCHK(hipMalloc((void **)&s->sym_items_dev, pl.items.size() * sizeof(SymItem)));
+    HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, bounds.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&s->sym_segs_dev, (pl.segs.size() ? pl.segs.size() : 1) * sizeof(SymSeg)));
     HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
     HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * s->esz));
-    HIPCHK(hipMemcpy(s->sym_items_dev, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_rowbase_dev, rowbase.data(), rowbase.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_segs_dev, segs.data(), segs.size() * sizeof(SymSeg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_items_dev, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_rowbase_dev, bounds.data(), bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_segs_dev, pl.segs.data(), pl.segs.size() * sizeof(SymSeg), hipMemcpyHostToDevice));
     // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
     // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
     // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
     // same trick costs 4 % — profiles/r01_aux_stream_ab.log — hence the bound).  NB_SYM_AUX_STREAM=0/1 forces it.
     const char *auxenv = getenv("NB_SYM_AUX_STREAM");
-    if (s->sym_sharded && (auxenv ? atoi(auxenv) != 0 : s->sym_items_local <= 4u * (uint32_t)s->cus)) {
+    s->aux_local = s->sym_sharded && (auxenv ? atoi(auxenv) != 0 : s->sym_items_local <= 4u * (uint32_t)s->cus);
+    if (s->aux_local || s->sym_items_late) {         // the late items always run on the side stream
         HIPCHK(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_late, hipEventDisableTiming));
     }
     if (s->sym_sharded) {
         if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
@@ -449,6 +514,7 @@ static void free_all(nb_sim *s)
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_late) (void)hipEventDestroy(s->ev_late);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -698,39 +764,64 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
 
 // Sum of the slabs.  fuse_step (whole-system handles): apply kick and drift in the same kernel; otherwise the
 // summed (unsharded) or partial (sharded rank) acceleration of every particle is stored: slab 0 / acc_full.
+// A sharded rank's late items are left out here (launch_sym_gather_late folds them in).
 static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
 {
-    const uint32_t n = (uint32_t)s->n, gg = (n + GATHER_P - 1) / GATHER_P;
+    const uint32_t n = (uint32_t)s->n, gg = (n + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
     void *dst = s->sym_sharded ? s->acc_full : s->partial;
+    const uint32_t *lo = s->sym_rowbase_dev, *hi = s->sym_rowbase_dev + tiles;      // [first row, first late row)
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
     if (s->dims3) {
         const float4 *ss = (const float4 *)s->sym_slab_s, *sr = (const float4 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
                                                            (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
                                                            (float)dt, (float)dt, kd);
         else
-            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
                                                             nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0);
     } else if (s->fp64) {
         const double2 *ss = (const double2 *)s->sym_slab_s, *sr = (const double2 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (double2 *)dst,
+            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (double2 *)dst, nullptr,
                                                                   (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
                                                                   dt, dt, s->p.extras, kd);
         else
-            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (double2 *)dst,
+            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (double2 *)dst, nullptr,
                                                                    nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
     } else {
         const float2 *ss = (const float2 *)s->sym_slab_s, *sr = (const float2 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float2 *)dst,
+            sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (float2 *)dst, nullptr,
                                                                  (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
                                                                  (float)dt, (float)dt, s->p.extras, kd);
         else
-            sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, s->sym_rowbase_dev, s->sym_segs_dev, s->sym_nsegs, n, (float2 *)dst,
+            sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (float2 *)dst, nullptr,
                                                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
     }
+    HIPCHK(hipGetLastError());
+    return NB_OK;
+}
+
+// Sharded rank, after the reduce-scatter: acceleration of the owned block = acc_owned (the summed partials of all
+// ranks) + the slabs of this rank's late items; kick and drift applied in the same kernel.
+static int launch_sym_gather_late(nb_sim *s, double dt)
+{
+    const uint32_t n = (uint32_t)s->n, ic = (uint32_t)s->i_count, ib = (uint32_t)s->i_begin;
+    const uint32_t gg = (ic + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
+    const uint32_t *lo = s->sym_rowbase_dev + tiles, *hi = s->sym_rowbase_dev + 2 * (size_t)tiles;   // [first late row, end row)
+    const SymSeg *segs = s->sym_segs_dev + s->sym_nsegs;
+    const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
+    if (s->fp64)
+        sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, lo, hi, segs,
+                                                              s->sym_nsegs_late, n, ib, ic, nullptr, (const double2 *)s->acc_owned,
+                                                              (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
+                                                              dt, dt, s->p.extras, kd);
+    else
+        sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>((const float2 *)s->sym_slab_s, (const float2 *)s->sym_slab_r, lo, hi, segs,
+                                                             s->sym_nsegs_late, n, ib, ic, nullptr, (const float2 *)s->acc_owned,
+                                                             (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
+                                                             (float)dt, (float)dt, s->p.extras, kd);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
@@ -847,7 +938,7 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     if (s->sym_sharded) {
         // pairs inside my own block: no remote data needed.  On the side stream (ordered after everything
         // enqueued so far), so the cross items of nb_step_mid fill the CUs its last workgroups leave idle.
-        if (!s->aux) return launch_sym_items(s, 0, s->sym_items_local);
+        if (!s->aux_local) return launch_sym_items(s, 0, s->sym_items_local);
         HIPCHK(hipEventRecord(s->ev_fork, s->stream));
         HIPCHK(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
         const int rc = launch_sym_items(s, 0, s->sym_items_local, s->aux);
@@ -867,10 +958,18 @@ extern "C" int nb_step_mid(nb_sim *s)
     if (!s->sym_sharded) return NB_OK;                 // nothing between begin and finish in the other protocols
     if (s->mid_done) { nb_set_error("nb_step_mid: already called for this step"); return NB_ESTATE; }
     if (bind(s)) return NB_EHIP;
-    int rc = launch_sym_items(s, s->sym_items_local, s->sym_items - s->sym_items_local);   // cross-block pairs: need the gathered positions
+    int rc = launch_sym_items(s, s->sym_items_local, s->sym_items_cross);   // cross-block pairs: need the gathered positions
     if (rc) return rc;
     s->mid_done = true;
-    if (s->aux) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));   // the local items' slabs
+    if (s->sym_items_late) {
+        // the held-back local items go to the side stream once the cross items are through: they run while the
+        // host's reduce-scatter of acc_full is in flight and are folded in by nb_step_finish
+        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+        if ((rc = launch_sym_items(s, s->sym_items_local + s->sym_items_cross, s->sym_items_late, s->aux))) return rc;
+        HIPCHK(hipEventRecord(s->ev_late, s->aux));
+    }
+    if (s->aux_local) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));   // the local items' slabs
     return launch_sym_gather(s, false, 0.0);           // partial acceleration of every particle -> acc_full
 }
 
@@ -889,7 +988,10 @@ extern "C" int nb_step_finish(nb_sim *s)
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
         const int nxt = s->cur ^ 1;
         const float dt = s->pending_dt;
-        if (s->fp64)
+        if (s->sym_items_late) {
+            HIPCHK(hipStreamWaitEvent(s->stream, s->ev_late, 0));
+            if ((rc = launch_sym_gather_late(s, (double)dt))) return rc;
+        } else if (s->fp64)
             integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
                                                                  (double2 *)s->acc, (const double2 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic,
                                                                  (double)dt, (double)dt, s->p.extras, INTEG_KICK | INTEG_DRIFT);
@@ -1202,12 +1304,12 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u late=%u | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
-             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->cus);
+             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->sym_items_late, s->cus);
     return NB_OK;
 }

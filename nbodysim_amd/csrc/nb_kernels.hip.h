@@ -529,14 +529,19 @@ struct SymSeg { uint32_t row, lo, hi, tile; };
 constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
 
 // FUSE: the summed acceleration goes straight into kick_drift_one (whole-system handles: the owned
-// block is everything), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum
-// (sharded ranks: the partial of every particle, to be reduce-scattered).
+// block is everything; sharded ranks: the LATE local items' slabs on top of the reduce-scattered sum
+// `base`), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum (sharded ranks:
+// the partial of every particle, to be reduce-scattered).
+// The launch covers particles [k0, k0 + kn); tile g's stationary rows are [row_lo[g], row_hi[g]).
 template <typename real, bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
                 const typename vec2_of<real>::type *__restrict__ slab_r,
-                const uint32_t *__restrict__ rowbase, const SymSeg *__restrict__ segs, uint32_t nsegs,
-                uint32_t n, typename vec2_of<real>::type *__restrict__ acc_sum,
+                const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
+                const SymSeg *__restrict__ segs, uint32_t nsegs,
+                uint32_t n, uint32_t k0, uint32_t kn,
+                typename vec2_of<real>::type *__restrict__ acc_sum,
+                const typename vec2_of<real>::type *__restrict__ base,
                 const typename vec2_of<real>::type *__restrict__ pos_cur,
                 typename vec2_of<real>::type *__restrict__ pos_next,
                 typename vec2_of<real>::type *__restrict__ vel,
@@ -546,11 +551,11 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     typedef typename vec2_of<real>::type real2;
     __shared__ real2 part[GATHER_Q][GATHER_P];
     const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
-    const uint32_t k = blockIdx.x * GATHER_P + p;
+    const uint32_t li = blockIdx.x * GATHER_P + p, k = k0 + li;
     real2 a; a.x = 0; a.y = 0;
-    if (k < n) {
+    if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
-        const uint32_t r0 = rowbase[g], r1 = rowbase[g + 1];
+        const uint32_t r0 = row_lo[g], r1 = row_hi[g];
         for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
             const real2 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y;
@@ -564,11 +569,12 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     }
     part[q][p] = a;
     __syncthreads();
-    if (q == 0 && k < n) {
+    if (q == 0 && li < kn) {
         real2 t = part[0][p];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][p].x; t.y += part[j][p].y; }
-        if constexpr (FUSE) kick_drift_one<real, false>(t, k, pos_cur, pos_next, vel, acc, 0u, dt_kick, dt_drift, extras, flags);
+        if (base) { const real2 b = base[li]; t.x += b.x; t.y += b.y; }
+        if constexpr (FUSE) kick_drift_one<real, false>(t, li, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
         else acc_sum[k] = t;
     }
 }

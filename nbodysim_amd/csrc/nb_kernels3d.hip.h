@@ -283,7 +283,8 @@ void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ 
 template <bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ slab_r,
-                 const uint32_t *__restrict__ rowbase, const SymSeg *__restrict__ segs, uint32_t nsegs, uint32_t n,
+                 const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
+                 const SymSeg *__restrict__ segs, uint32_t nsegs, uint32_t n,
                  float4 *__restrict__ acc_sum, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
                  float4 *__restrict__ vel, float4 *__restrict__ acc, float dt_kick, float dt_drift, int flags)
 {
@@ -293,7 +294,7 @@ void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ s
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < n) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
-        for (uint32_t r = rowbase[g] + q; r < rowbase[g + 1]; r += GATHER_Q) {
+        for (uint32_t r = row_lo[g] + q; r < row_hi[g]; r += GATHER_Q) {
             const float4 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }

@@ -91,6 +91,9 @@ int main(int argc, char **argv)
             if (!h[r]) DIE("nb_create(shard %d): %s", r, nb_last_error());
         }
         const int symmetric = nb_shard_protocol(h[0]) == NB_SHARD_SYMMETRIC;
+        char desc0[640];
+        CHECK(nb_describe(h[0], desc0, sizeof desc0));
+        printf("shard 0: %s\n", desc0);
         const double t0s = now_s();
         for (int s = 0; s < steps; ++s) {
             for (int r = 0; r < shards; ++r) CHECK(nb_step_begin(h[r], p.dt));

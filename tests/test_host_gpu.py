@@ -1,6 +1,7 @@
 """GPU: the compiled hosts over the C ABI — the plain-C driver, the C++ `Simulation`
 adaptor driven with the reference's simulation_thread pattern (main.cpp:612-635) —
 and the page-locked nb_sync path."""
+import os
 import re
 import subprocess
 
@@ -72,16 +73,20 @@ def test_sync_into_page_locked_host_memory_is_identical():
             L.check("nb_host_unregister", lib.nb_host_unregister(pinned.ctypes.data))
 
 
-@pytest.mark.parametrize("n,protocol", [(8192, "allgather"), (65536, "symmetric")])
-def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, protocol):
+@pytest.mark.parametrize("n,protocol,late_us", [(8192, "allgather", None), (65536, "symmetric", None), (65536, "symmetric", "40")])
+def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, protocol, late_us):
     """`nbody_main -shards 4`: four sharded handles in one C process, exchanged with
     nb_exchange_positions / nb_exchange_accelerations (the multi-GPU-without-RCCL host);
     same trajectory as one handle, in both sharding protocols."""
     exe = ROOT / "build" / "nbody_main"
     dump = tmp_path / "sh.nbd"
+    env = dict(os.environ)
+    if late_us:
+        env["NB_SYM_LATE_US"] = late_us       # hold local items back for the side stream (default from 8 ranks on)
     r = subprocess.run([str(exe), "-n", str(n), "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)],
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert ("late=0" not in r.stdout) == bool(late_us) or protocol == "allgather"
     assert "shards=4" in r.stdout and "frame=6" in r.stdout and f"protocol={protocol}" in r.stdout
     back, frame, _ = nb.read_bodies(dump)
     with nb.Simulation(nb.plummer_2d(n, 42), eps=0.05) as sim:
