@@ -177,13 +177,15 @@ def main() -> None:
         value = pairs_per_step * args.steps / elapsed
         # force launches per step on this rank: 1 (single GPU) or up to 3 (local + remote ranges)
         pairs_this_rank = float(inner.i_count) * float(n) * args.steps
-        if launches and force_ms > 0:
+        if launches and force_ms > 0 and world == 1:
             kern_s = force_ms * 1e-3
             achieved = flop_per_pair * pairs_this_rank / kern_s / 1e12
             avg_launch_ms = force_ms / launches
         else:
+            # sharded ranks run their force launches on two streams at once (their event intervals overlap), so the
+            # per-rank figure is taken over the wall time of the step, collectives included
             achieved = flop_per_pair * pairs_this_rank / elapsed / 1e12
-            avg_launch_ms = None
+            avg_launch_ms = force_ms / launches if launches else None
         traffic = None
         tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived, written by tools/collect_profile.sh
         if tfile.exists() and world == 1 and n == N_DEFAULT:
