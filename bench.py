@@ -234,6 +234,9 @@ def main() -> None:
                         "once (Newton's third law), so it executes fewer flops than it delivers; "
                         "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B",
                 "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
+                # measured HBM rate of the kernel: PMC bytes per launch (profiles/hbm_traffic.json) over its duration
+                "measured_hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
+                "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic) if traffic else None,
             },
             "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                        "steps": args.warmup + args.steps},
