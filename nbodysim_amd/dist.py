@@ -80,6 +80,17 @@ def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False
     return dist.all_gather_into_tensor(full, own, group=group, async_op=async_op)
 
 
+def reduce_accelerations(acc_full, acc_owned, plan: ShardPlan, group=None) -> None:
+    """Sum the ranks' partial accelerations ``acc_full`` (n, 2); every rank keeps its own block in ``acc_owned``."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(acc_owned, acc_full, op=dist.ReduceOp.SUM, group=group)
+    else:   # gloo has no reduce-scatter: all-reduce, then keep the owned rows
+        dist.all_reduce(acc_full, op=dist.ReduceOp.SUM, group=group)
+        acc_owned.copy_(acc_full[plan.i_begin : plan.i_end])
+
+
 class DistributedSimulation:
     """Sharded ``Simulation``: one rank of a ``torch.distributed`` job, one GPU."""
 
@@ -128,12 +139,7 @@ class DistributedSimulation:
 
     def _reduce_accelerations(self) -> None:
         """Sum the ranks' partial accelerations; every rank keeps its own block."""
-        backend = self.dist.get_backend(self.group)
-        if backend == "nccl":
-            self.dist.reduce_scatter_tensor(self.acc_owned, self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)
-        else:   # gloo has no reduce-scatter: all-reduce, then keep the owned rows
-            self.dist.all_reduce(self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.acc_owned.copy_(self.acc_full[self.plan.i_begin : self.plan.i_end])
+        reduce_accelerations(self.acc_full, self.acc_owned, self.plan, self.group)
 
     def step(self, dt: Optional[float] = None) -> None:
         """One sharded step; only enqueues (no host sync)."""

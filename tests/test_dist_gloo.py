@@ -95,3 +95,81 @@ def test_two_rank_gloo_sharded_steps_match_unsharded_oracle(tmp_path, steps, gol
         v = np.load(tmp_path / f"vel_rank{r}.npy")
         lo, hi = r * n // world, (r + 1) * n // world
         assert np.array_equal(v.view(np.uint32), want_vel[lo:hi].view(np.uint32))
+
+
+def _sym_worker(rank, world, port, n, steps, out_dir):
+    """The symmetric protocol's data flow on CPU: this rank's share of the UNORDERED pairs (the product planner's
+    items, read through nb_debug_sym_plan — a host-only entry) evaluated with numpy in fp64, partial accelerations
+    of all particles summed across ranks with dist.reduce_accelerations, owned block kicked and drifted, positions
+    all-gathered in place with dist.exchange_positions."""
+    import ctypes as C
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd.dist import ShardPlan, exchange_positions, reduce_accelerations
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = nb.load()
+        cnt, nloc, L = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert lib.nb_debug_sym_plan(n, 256, rank, world, None, 0, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
+        items = np.zeros((cnt.value, 8), np.uint32)
+        assert lib.nb_debug_sym_plan(n, 256, rank, world, items.ctypes.data, cnt.value, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
+        ic = nb.plummer_2d(n, 11)
+        m = ic["mass"].astype(np.float64)
+        plan = ShardPlan(n, world, rank)
+        lo, hi = plan.i_begin, plan.i_end
+        eps2, dt = 0.05 ** 2, 1e-3
+        pos = [torch.from_numpy(ic["pos"].astype(np.float64).copy()) for _ in range(2)]
+        vel = ic["vel"].astype(np.float64)[lo:hi].copy()
+        cur, pending = 0, None
+        for _ in range(steps):
+            if pending is not None:
+                pending.wait()
+                pending = None
+            x = pos[cur].numpy()
+            acc_full = np.zeros((n, 2))
+            for tile, c0, c, s_row, r_row, diag, group, _ in items:
+                S = slice(tile * 2048, min((tile + 1) * 2048, n))
+                T = slice(c0 * 64, min((c0 + c) * 64, n))
+                d = x[None, T, :] - x[S, None, :]                       # r = p_j - p_i (Quadtree.hpp:136)
+                inv3 = (d[..., 0] ** 2 + d[..., 1] ** 2 + eps2) ** -1.5
+                acc_full[S] += np.einsum("ij,ijk->ik", inv3 * m[None, T], d)
+                if not diag:                                            # Newton's third law: the same pairs, other end
+                    acc_full[T] -= np.einsum("ij,ijk->jk", inv3 * m[S, None], d)
+            full_t, own_t = torch.from_numpy(acc_full), torch.zeros((hi - lo, 2), dtype=torch.float64)
+            reduce_accelerations(full_t, own_t, plan)
+            vel += own_t.numpy() * dt
+            nxt = pos[cur ^ 1]
+            nxt[lo:hi] = torch.from_numpy(x[lo:hi] + vel * dt)
+            cur ^= 1
+            pending = exchange_positions(pos[cur], plan, async_op=True)
+        if pending is not None:
+            pending.wait()
+        np.save(Path(out_dir) / f"sympos_rank{rank}.npy", pos[cur].numpy())
+        np.save(Path(out_dir) / f"symvel_rank{rank}.npy", vel)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_symmetric_protocol_matches_unsharded_fp64(tmp_path, nbo):
+    """world_size 2 over gloo on CPU, the reduce-scatter + all-gather protocol of the benchmark with the product's
+    own pair split: identical (to fp64 rounding) to the unsharded fp64 direct sum."""
+    import torch.multiprocessing as mp
+
+    import nbodysim_amd as nb
+    n, world, steps = 8192, 2, 2
+    mp.spawn(_sym_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    ic = nb.plummer_2d(n, 11)
+    st = nbo.step_f64(nbo.state_from_bodies(ic, np.float64), 0.05, 1e-3, steps)
+    want_pos, want_vel = np.stack([st["x"], st["y"]], 1), np.stack([st["vx"], st["vy"]], 1)
+    for r in range(world):
+        got = np.load(tmp_path / f"sympos_rank{r}.npy")
+        assert np.max(np.abs(got - want_pos)) < 1e-12 * np.max(np.abs(want_pos))        # complete replica on every rank
+        v = np.load(tmp_path / f"symvel_rank{r}.npy")
+        blk = slice(r * n // world, (r + 1) * n // world)
+        assert np.max(np.abs(v - want_vel[blk])) < 1e-11 * np.max(np.abs(want_vel))
