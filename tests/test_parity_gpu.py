@@ -649,3 +649,41 @@ def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
     assert max_rel(got["vel"], v1) < 1e-5 and max_rel(got["pos"], x1) < 1e-6
     with nb.Simulation(ic, eps=0.01) as sim:
         assert "symmetric=0" in sim.describe()          # 2049 travelling rows x n x 8 B = 64 GiB > cap
+
+
+@pytest.mark.parametrize("late_us,aux", [("0", "0"), ("40", "0"), ("40", "1")])
+def test_symmetric_sharded_handles_in_process_match_unsharded(monkeypatch, late_us, aux):
+    """Two NB_SHARD_SYMMETRIC handles of N = 131 072 driven from this process (nb_exchange_accelerations /
+    nb_exchange_positions): with and without the held-back local items, local items on the main or the side stream."""
+    import ctypes
+    monkeypatch.setenv("NB_SYM_LATE_US", late_us)
+    monkeypatch.setenv("NB_SYM_AUX_STREAM", aux)
+    lib = nb.load()
+    n, parts, steps = 131072, 2, 3
+    ic = nb.plummer_2d(n, 8)
+    with nb.Simulation(ic, eps=0.02) as sim:
+        sim.advance(steps, 1e-3)
+        whole = sim.sync()
+    blk = n // parts
+    sims = [nb.Simulation(ic, eps=0.02, i_begin=r * blk, i_count=blk, shard_rank=r, shard_world=parts) for r in range(parts)]
+    try:
+        assert all(s.shard_protocol == L.NB_SHARD_SYMMETRIC for s in sims)
+        assert all(("late=0" in s.describe()) == (late_us == "0") for s in sims)
+        handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
+        for _ in range(steps):
+            for s in sims:
+                s.step_begin(1e-3)
+            for s in sims:
+                s.step_mid()
+            L.check("nb_exchange_accelerations", lib.nb_exchange_accelerations(handles, parts))
+            for s in sims:
+                s.step_finish()
+            L.check("nb_exchange_positions", lib.nb_exchange_positions(handles, parts))
+        out = nb.bodies_array(n)
+        for s in sims:
+            out[s.i_begin : s.i_begin + s.i_count] = s.sync()
+    finally:
+        for s in sims:
+            s.close()
+    assert max_rel(out["pos"], whole["pos"]) < 2e-6 and max_rel(out["vel"], whole["vel"]) < 2e-5
+    assert max_rel(out["acc"], whole["acc"]) < 1e-4
