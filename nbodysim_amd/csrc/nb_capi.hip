@@ -283,7 +283,9 @@ static void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t wor
         if (I / tpb == rank || world == 1) local += be - I * cpt;                 // own chunks (diagonal) + later chunks of the block
         cross_total += chunks - be;
     }
-    const uint32_t target = (world > 1 ? 16u : 32u) * cus;                        // workgroups wanted (profiles/r01_*sweep.log)
+    // workgroups wanted (profiles/r01_*sweep.log): with the guided tail 24 per CU run as fast as 32 (L = 43-48 vs 33
+    // at N = 262 144) and write a quarter fewer slab rows
+    const uint32_t target = (world > 1 ? 16u : 24u) * cus;
     // Chunks per item.  Large systems: as many items as fill the chip `target` workgroups deep.  Small ones
     // (fewer chunk-units than that): one chunk per item would be the finest grain, but every item costs a
     // 16-KiB slab row that sym_gather re-reads and a prologue, while coarse items cost tail — the optimum

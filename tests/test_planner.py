@@ -87,7 +87,7 @@ def test_forced_late_items_keep_the_cover_exact(monkeypatch, world):
 
 
 def test_plan_fills_the_chip():
-    for n, world, lo, hi in ((262144, 1, 6000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 1400)):
+    for n, world, lo, hi in ((262144, 1, 5000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 1400)):
         items, nloc, L = plan(n, world // 2, world)
         assert lo <= len(items) <= hi, (n, world, len(items), L)
 

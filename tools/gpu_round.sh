@@ -22,9 +22,11 @@ for what in "$@"; do
     benchq) stage 300 gpurun_out/bench.log python bench.py --steps 20 --warmup 3 --no-cpu-baseline; tail -2 gpurun_out/bench.log ;;
     cmain)  stage 300 gpurun_out/cmain.log ./build/nbody_main -n 262144 -s 20; tail -5 gpurun_out/cmain.log ;;
     prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+            rm -rf gpurun_out/prof
             stage 600 gpurun_out/rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
             tail -3 gpurun_out/rocprof_stats.log; find gpurun_out/prof -name '*stats*' | head ;;
     pmc)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+            rm -rf gpurun_out/pmc
             for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
                        "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS" \
                        "GRBM_GUI_ACTIVE GRBM_COUNT FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
