@@ -16,12 +16,22 @@ from nbodysim_amd import _lib as L
 pytestmark = pytest.mark.gpu
 
 
+def _host_program(name):
+    """build/<name>; built by __graft_entry__.build(), rebuilt here (plain gcc/g++ against the in-tree library) if absent."""
+    exe = ROOT / "build" / name
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(ROOT / "nbodysim_amd" / "host")], check=True, capture_output=True, timeout=300)
+    assert exe.exists()
+    return exe
+
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
 def test_c_driver_runs_and_its_dump_matches_the_python_path(tmp_path):
-    exe = ROOT / "build" / "nbody_main"
+    exe = _host_program("nbody_main")
     assert exe.exists(), "build() must produce build/nbody_main"
     dump = tmp_path / "c.nbd"
     r = subprocess.run([str(exe), "-n", "4096", "-s", "10", "-sync-every", "1", "-dump", str(dump)],
@@ -40,7 +50,7 @@ def test_c_driver_runs_and_its_dump_matches_the_python_path(tmp_path):
 
 
 def test_cxx_adaptor_with_reference_caller_pattern():
-    exe = ROOT / "build" / "sim_thread_example"
+    exe = _host_program("sim_thread_example")
     assert exe.exists()
     r = subprocess.run([str(exe), "2048"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -78,7 +88,7 @@ def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, prot
     """`nbody_main -shards 4`: four sharded handles in one C process, exchanged with
     nb_exchange_positions / nb_exchange_accelerations (the multi-GPU-without-RCCL host);
     same trajectory as one handle, in both sharding protocols."""
-    exe = ROOT / "build" / "nbody_main"
+    exe = _host_program("nbody_main")
     dump = tmp_path / "sh.nbd"
     env = dict(os.environ)
     if late_us:
@@ -98,7 +108,7 @@ def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, prot
 
 def test_cxx_default_constructed_simulation_is_the_reference_start():
     """`std::make_shared<Simulation>()` as in main.cpp:657: 25 000-body disc, eps = 1, dt = SIMULATION_DT = 0.01."""
-    exe = ROOT / "build" / "sim_thread_example"
+    exe = _host_program("sim_thread_example")
     r = subprocess.run([str(exe), "reference", "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"frame=(\d+) bodies=(\d+) body1=\(([-0-9.e+]+), ([-0-9.e+]+)\) last=\(([-0-9.e+]+), ([-0-9.e+]+)\)", r.stdout)
