@@ -629,7 +629,7 @@ def test_reference_full_default_start_through_the_gpu_path(nbo):
 def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
     """Index arithmetic far beyond the BASELINE sizes: a handle that owns the LAST 4096 + 77 particles of
     n = 4 194 381 (ragged: not a multiple of any tile) computes their accelerations from all n bodies; the CPU
-    fp64 direct sum over the same i-range (1.7e10 pairs) is the check.  Also the symmetric path's 8 GiB slab cap:
+    fp64 direct sum over the same i-range (1.7e10 pairs) is the check.  Also the symmetric path's 48 GiB slab cap:
     a whole-system handle of this size must choose the one-sided kernel."""
     n, own = (1 << 22) + 77, 4096 + 77
     ic = nb.plummer_2d(n, 3)
@@ -649,6 +649,30 @@ def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
     assert max_rel(got["vel"], v1) < 1e-5 and max_rel(got["pos"], x1) < 1e-6
     with nb.Simulation(ic, eps=0.01) as sim:
         assert "symmetric=0" in sim.describe()          # 2049 travelling rows x n x 8 B = 64 GiB > cap
+
+
+def test_two_million_bodies_symmetric_kernel_properties():
+    """N = 2 097 152 on one GPU: 1024 tiles, 16 GiB of travelling slabs (sized for 288 GB of HBM).  One step:
+    total momentum change zero, energy steady, and the last tile's accelerations equal to the one-sided kernel's."""
+    n = 1 << 21
+    ic = nb.plummer_2d(n, 5)
+    m = ic["mass"].astype(np.float64)[:, None]
+    with nb.Simulation(ic, eps=0.01) as sim:
+        assert "symmetric=1" in sim.describe()
+        k0, u0 = sim.energy()
+        sim.advance(1, 1e-3)
+        k1, u1 = sim.energy()
+        b = sim.sync()
+    acc = b["acc"].astype(np.float64)
+    f = (m * acc).sum(0)
+    assert (np.abs(f) < 1e-5 * np.abs(m * acc).sum(0)).all()
+    assert abs((k1 + u1 - k0 - u0) / (k0 + u0)) < 1e-5
+    own = 4096
+    with nb.Simulation(ic, eps=0.01, i_begin=n - own, i_count=own) as one:      # one-sided kernel on the last block
+        one.step_begin(1e-3)
+        one.step_finish()
+        ref = one.sync()["acc"].astype(np.float64)
+    assert np.max(np.abs(acc[n - own:] - ref)) < 2e-5 * np.max(np.abs(ref))
 
 
 @pytest.mark.parametrize("late_us,aux", [("0", "0"), ("40", "0"), ("40", "1")])
