@@ -207,7 +207,7 @@ static void plan(nb_sim *s)
 {
     const uint32_t n = (uint32_t)s->n, ib = (uint32_t)s->i_begin, ic = (uint32_t)s->i_count;
     s->job_all = plan_job(s, 0, n, 0);
-    s->slabs_all = want_sym(s) ? 1 : s->job_all.js;      // the symmetric path leaves one summed slab
+    s->slabs_all = s->sym ? 1 : s->job_all.js;           // the symmetric path leaves one summed slab
     s->job_local = plan_job(s, ib, ib + ic, 0);
     // everything but the owned block, in one launch: virtual j range [0, n - ic) with a gap at the block
     s->job_remote = plan_job(s, 0, n - ic, s->job_local.js, ib, ic);
@@ -618,6 +618,9 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (p.stream) { s->stream = (hipStream_t)p.stream; s->own_stream = false; }
     else { if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e); s->own_stream = true; }
 
+    // decided once (eligibility looks at the free device memory, which the allocations below change)
+    s->sym = want_sym(s);
+    s->sym_sharded = want_sym_sharded(s);
     plan(s);
     const size_t r2 = s->esz;
     if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; }
@@ -635,8 +638,6 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->ered_blocks = (s->i_count + BLOCK - 1) / BLOCK;
     if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
 
-    s->sym = want_sym(s);
-    s->sym_sharded = want_sym_sharded(s);
     if ((s->sym || s->sym_sharded) && plan_sym(s) != NB_OK) { free_all(s); return nullptr; }
     if (do_upload(s, init) != NB_OK) { free_all(s); return nullptr; }
     return s;
