@@ -229,9 +229,14 @@ static bool sym_eligible(const nb_sim *s)
     const size_t rrows = world == 1 ? tiles : 2 * tiles / world + 2;            // travelling rows held by one handle
     // travelling slabs: sized for the 288 GB of an MI355X — up to 48 GiB and a third of what is free now
     // (N = 1 048 576: 4 GiB; N ~ 3.5 million fp32 is the largest symmetric run; beyond that the one-sided kernel)
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)24 << 30; }
-    const size_t cap = free_b / 3 < ((size_t)48 << 30) ? free_b / 3 : ((size_t)48 << 30);
+    // Ranks of a sharded run must all take the same decision (it selects the exchange protocol), so there the
+    // limit does not look at this device's free memory; an allocation that does not fit fails nb_create loudly.
+    size_t cap = (size_t)48 << 30;
+    if (world == 1) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)24 << 30; }
+        if (free_b / 3 < cap) cap = free_b / 3;
+    }
     if (rrows * s->n * s->esz > cap) return false;
     return true;
 }
