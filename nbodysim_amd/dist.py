@@ -129,6 +129,11 @@ class DistributedSimulation:
             shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs,
         )
         self.symmetric = self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
+        if world > 1:   # the protocol fixes which collectives a step issues: every rank must have chosen the same one
+            t = torch.tensor([self.sim.shard_protocol, -self.sim.shard_protocol], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError("sharding protocol differs between ranks (different environment or device?)")
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
