@@ -11,11 +11,14 @@
  * Error convention (the reference has none — void returns, no exceptions):
  * int-returning functions give 0 on success and a negative NB_E* code on
  * failure; pointer-returning functions give NULL; nb_last_error() holds the
- * text for the calling thread.  A handle is not thread-safe (the reference's
+ * text and nb_last_error_code() the NB_E* code of the last failure on the
+ * calling thread (so a NULL from nb_create still tells NB_ENODEVICE from
+ * NB_ENOMEM from NB_EINVAL).  A handle is not thread-safe (the reference's
  * Simulation is single-caller too, main.cpp:621).
  *
  * There is NO CPU fallback: without a HIP device nb_create() fails with
- * NB_ENODEVICE.
+ * NB_ENODEVICE.  The library reads NO environment variables: every switch is a
+ * field of nb_params.
  */
 #ifndef NBODY_H
 #define NBODY_H
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 
 /* ---- particle record -------------------------------------------------------
  * Bit-compatible with the reference's `struct alignas(16) Body`
@@ -95,6 +98,12 @@ enum { NB_EXTRA_VCLAMP   = 1,   /* |v| <= 1000,            Simulation.hpp:133-13
 enum { NB_INTEGRATOR_KICK_DRIFT = 0, /* Simulation.hpp:129-131,160-163 (reference) */
        NB_INTEGRATOR_KDK = 1 };      /* kick-drift-kick leapfrog (build extension) */
 
+/* nb_params.flags bit mask: algorithm switches (all 0 = the fast defaults) */
+enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered pair evaluated); a sharded
+                                         handle then uses the NB_SHARD_ALLGATHER protocol */
+       NB_FLAG_NO_UNIFORM_MASS = 2,   /* keep the per-pair mass multiply even when all masses are equal */
+       NB_FLAG_NO_GUIDED_TAIL  = 4 }; /* symmetric planner: uniform work items (no finer items at the end) */
+
 /* ---- parameters ----------------------------------------------------------- */
 typedef struct nb_params {
     uint32_t struct_size;  /* = sizeof(nb_params); set by nb_params_default */
@@ -123,8 +132,18 @@ typedef struct nb_params {
                               NULL = allocated by the library */
     int32_t  dims;         /* 2 (default, the reference) or 3: build extension — z of
                               pos / vel / acc lives in the first padding float of each vector
-                              (macro NB_Z), sizeof of a body stays 64; fp32, tiled, unsharded only */
-    int32_t  reserved0;
+                              (macro NB_Z), sizeof of a body stays 64; tiled sum, no extras */
+    int32_t  flags;        /* NB_FLAG_* bit mask */
+    /* Tuning of the launch geometry; 0 = automatic everywhere (what the measurements in profiles/ chose).
+     * Ranks of one sharded run must pass identical values: they select the pair split (nb_sym_info). */
+    int32_t  sym_chunks_per_item; /* symmetric kernel: 64-particle chunks per work item (L) */
+    int32_t  sym_aux_stream;      /* sharded symmetric: local items on a side stream: 0 auto, 1 always, -1 never */
+    float    sym_late_us;         /* sharded symmetric: whole-chip microseconds of local work held back to run
+                                     beside the reduce-scatter: 0 auto (40 us from 8 ranks on), < 0 none */
+    int32_t  lanes_p;             /* one-sided kernel: packed particle pairs per lane (1, 2, 4) */
+    float    sym_tail[3];         /* guided-tail thresholds (fractions of a launch's work from which items are cut
+                                     into L/2, L/4, L/8 chunks); all 0 = 0.85, 0.94, 0.98 */
+    int32_t  reserved1;
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
@@ -274,19 +293,45 @@ int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
  * radius, near-circular speeds; bit-identical to the compiled reference (tests/golden/default_ics.json). */
 int nb_default_ics(nb_body *out, size_t n);
 
-/* Host-only view of the symmetric kernel's work planner (no GPU needed; used by the CPU tests to check
- * that the items of all ranks cover every unordered (tile, chunk) pair exactly once and are balanced).
- * items_out receives up to cap items of 8 uint32: tile, first chunk, chunk count, stationary slab row,
- * travelling slab row, diagonal flag, 0, 0; the first *n_local items are the rank's LOCAL items (pairs
- * inside its own block), the rest its run of cross-block items.  Tiles are 2048 particles, chunks 64. */
-int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
-                      uint32_t *n_items, uint32_t *n_local, uint32_t *chunks_per_item);
+/* ---- the symmetric kernel's work plan ------------------------------------------ */
+/* One work item (= one workgroup of force_sym_*): tile `tile` (2048 particles) against the 64-particle
+ * chunks [c0, c0 + cnt).  s_row: row of the stationary slab it writes; the travelling partial of particle
+ * j goes to element r_base + j of the travelling slab (diag items write none); group: 0 = local (pairs
+ * inside the rank's own block), 1 = cross-block, 2 = late (held-back local). */
+typedef struct nb_sym_item {
+    uint32_t tile, c0, cnt, s_row;
+    int64_t  r_base;
+    uint32_t diag, group;
+} nb_sym_item;
+
+/* Figures of a plan.  Everything that must agree between the ranks of a sharded run (they split one set of
+ * pairs between them) is here, so a host can verify the agreement before the first step. */
+typedef struct nb_sym_info {
+    uint32_t struct_size;       /* = sizeof(nb_sym_info), set by the caller */
+    int32_t  enabled;           /* 1 = the handle runs the symmetric kernel */
+    uint32_t chunks_per_item;   /* L */
+    uint32_t items, items_local, items_cross, items_late;
+    uint32_t tiles, rows_s, segments, cus;
+    uint64_t units_local, units_cross, units_late;   /* (tile, chunk) units of each group */
+    uint64_t cross_units_total; /* cross-block units of ALL ranks: equal on every rank of a run */
+    uint64_t slab_s_bytes, slab_r_bytes;             /* the two partial-sum slab sets (written once, read once per step) */
+    uint64_t coverage_entries;
+} nb_sym_info;
+int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out);
+
+/* Host-only view of the planner (no GPU needed; used by the CPU tests to check that the items of all ranks
+ * cover every unordered (tile, chunk) pair exactly once, that the slab ranges are disjoint, and the balance).
+ * `tuning` may be NULL (defaults) — only flags, sym_chunks_per_item, sym_late_us, sym_tail and precision are read.
+ * items_out receives up to cap items, local ones first, then cross, then late. */
+int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
+                      nb_sym_item *items_out, size_t cap, nb_sym_info *info);
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);
 
-/* Text of the last error on this thread ("" if none). */
+/* Text of the last error on this thread ("" if none) and its NB_E* code (NB_OK if none). */
 const char *nb_last_error(void);
+int nb_last_error_code(void);
 
 /* NB_ABI_VERSION the library was built with. */
 int nb_abi_version(void);

@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libnbody_hip.so"
 
-NB_ABI_VERSION = 1
+NB_ABI_VERSION = 2
 
 # enums (include/nbody.h)
 NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -28,6 +28,7 @@ NB_EXTRA_VCLAMP, NB_EXTRA_BOUNDARY = 1, 2
 NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
 NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC = 0, 1, 2
+NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL = 1, 2, 4
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(
@@ -79,8 +80,48 @@ class nb_params(C.Structure):
         ("shard_world", C.c_int32),
         ("acc_buffers", C.c_void_p * 2),
         ("dims", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("flags", C.c_int32),
+        ("sym_chunks_per_item", C.c_int32),
+        ("sym_aux_stream", C.c_int32),
+        ("sym_late_us", C.c_float),
+        ("lanes_p", C.c_int32),
+        ("sym_tail", C.c_float * 3),
+        ("reserved1", C.c_int32),
     ]
+
+
+class nb_sym_info(C.Structure):
+    """Figures of a handle's symmetric work plan (include/nbody.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("enabled", C.c_int32),
+        ("chunks_per_item", C.c_uint32),
+        ("items", C.c_uint32),
+        ("items_local", C.c_uint32),
+        ("items_cross", C.c_uint32),
+        ("items_late", C.c_uint32),
+        ("tiles", C.c_uint32),
+        ("rows_s", C.c_uint32),
+        ("segments", C.c_uint32),
+        ("cus", C.c_uint32),
+        ("units_local", C.c_uint64),
+        ("units_cross", C.c_uint64),
+        ("units_late", C.c_uint64),
+        ("cross_units_total", C.c_uint64),
+        ("slab_s_bytes", C.c_uint64),
+        ("slab_r_bytes", C.c_uint64),
+        ("coverage_entries", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size"}
+
+
+#: numpy view of ``nb_sym_item`` (32 bytes)
+SYM_ITEM_DTYPE = np.dtype([("tile", "<u4"), ("c0", "<u4"), ("cnt", "<u4"), ("s_row", "<u4"), ("r_base", "<i8"),
+                           ("diag", "<u4"), ("group", "<u4")])
+assert SYM_ITEM_DTYPE.itemsize == 32
 
 
 #: every symbol include/nbody.h declares: name -> (restype, argtypes)
@@ -120,7 +161,9 @@ PROTOTYPES = {
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_default_ics": (C.c_int, [C.c_void_p, C.c_size_t]),
-    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(nb_params), C.c_void_p, C.c_size_t, C.POINTER(nb_sym_info)]),
+    "nb_sym_plan_info": (C.c_int, [C.c_void_p, C.POINTER(nb_sym_info)]),
+    "nb_last_error_code": (C.c_int, []),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),
@@ -153,6 +196,22 @@ def load() -> C.CDLL:
 
 def last_error() -> str:
     return (load().nb_last_error() or b"").decode("utf-8", "replace")
+
+
+def last_error_code() -> int:
+    return int(load().nb_last_error_code())
+
+
+def sym_plan(n: int, cus: int = 256, rank: int = 0, world: int = 1, tuning: "nb_params | None" = None):
+    """Host-only planner view: (items as a SYM_ITEM_DTYPE array, info dict).  No GPU needed."""
+    lib = load()
+    info = nb_sym_info()
+    info.struct_size = C.sizeof(nb_sym_info)
+    tp = C.byref(tuning) if tuning is not None else None
+    check("nb_debug_sym_plan", lib.nb_debug_sym_plan(n, cus, rank, world, tp, None, 0, C.byref(info)))
+    items = np.zeros(info.items, SYM_ITEM_DTYPE)
+    check("nb_debug_sym_plan", lib.nb_debug_sym_plan(n, cus, rank, world, tp, items.ctypes.data, info.items, C.byref(info)))
+    return items, info.as_dict()
 
 
 def check(where: str, rc: int) -> None:

@@ -26,26 +26,14 @@ using namespace nbk;
 // ---------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-extern "C" void nb_set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-}
-extern "C" void nb_clear_error(void) { g_err[0] = 0; }
-extern "C" const char *nb_last_error(void) { return g_err; }
-extern "C" int nb_abi_version(void) { return NB_ABI_VERSION; }
+// (the thread-local error text / code and nb_params_default live in nb_host.c: plain C, shared with the CPU-only build)
+static int hip_code(hipError_t e) { return e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation ? NB_ENOMEM : NB_EHIP; }
 
 #define HIPCHK(call)                                                                  \
     do {                                                                              \
         hipError_t e_ = (call);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            nb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return NB_EHIP;                                                           \
-        }                                                                             \
+        if (e_ != hipSuccess)                                                         \
+            return nb_fail(hip_code(e_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
 extern "C" int nb_device_count(void)
@@ -53,22 +41,6 @@ extern "C" int nb_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
-}
-
-extern "C" void nb_params_default(nb_params *p)
-{
-    if (!p) return;
-    memset(p, 0, sizeof *p);
-    p->struct_size = (uint32_t)sizeof(nb_params);
-    p->eps = 1.0f;   // Simulation.hpp:59  quadtree(1.0f, 1.0f, 16)
-    p->dt = 0.01f;   // main.cpp:39        SIMULATION_DT{0.01f}
-    p->precision = NB_FP32;
-    p->rsqrt_mode = NB_RSQRT_EXACT;
-    p->sum_order = NB_SUM_TILED;
-    p->integrator = NB_INTEGRATOR_KICK_DRIFT;
-    p->extras = 0;
-    p->device = -1;
-    p->j_slices = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -119,10 +91,12 @@ struct nb_sim {
     // symmetric path (force_sym_f32): work items and its two slab sets
     bool sym = false;
     uint32_t sym_items = 0, sym_items_local = 0, sym_items_cross = 0, sym_items_late = 0;   // [local | cross | late]
-    uint32_t sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_nsegs = 0, sym_nsegs_late = 0;
+    uint32_t sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_cov_late_off = 0;
     SymItem *sym_items_dev = nullptr;          // local items first, then the cross-block items
     uint32_t *sym_rowbase_dev = nullptr;       // 3 x tiles: first row / first late row / end row of every tile
-    SymSeg *sym_segs_dev = nullptr;
+    uint32_t *sym_cov_begin_dev = nullptr;     // 2 x (tiles + 1): coverage-list bounds of the main and the late gather
+    SymCov *sym_cov_dev = nullptr;             // coverage entries: main lists, then (from sym_cov_late_off) the late ones
+    nb_sym_info sym_info{};
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
@@ -182,8 +156,7 @@ static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t sla
     const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (tools/force_bench.hip sweep)
     const uint32_t max_slices = 128;                            // bounds the slab traffic of `integrate`
     const uint32_t tiles = (jn + TJ - 1) / TJ;
-    const char *envp = getenv("NB_FORCE_P");
-    const int forced_p = envp ? atoi(envp) : 0;
+    const int forced_p = s->p.lanes_p > 0 ? s->p.lanes_p : 0;
     const int pmax = s->fp64 ? 2 : 4;
     // Largest P (most independent chains per lane, fewest LDS reads per pair) that still yields
     // at least half the wanted workgroups; P halves only when both i and j are scarce.
@@ -214,30 +187,30 @@ static void plan(nb_sim *s)
     s->slabs_two_phase = s->job_local.js + s->job_remote.js;
 }
 
-// Symmetric path: fp32 tiled runs with eps > 0 that are big enough to fill the chip with
-// (tile, chunk-range) items — either the whole system on one GPU, or (shard_world > 1) this rank's
-// share of the tiles of a sharded run.  NB_NO_SYMMETRY=1 forces the one-sided kernels.
+// Symmetric path: tiled runs with eps > 0 that are big enough to fill the chip with (tile, chunk-range)
+// items — either the whole system on one GPU, or (shard_world > 1) this rank's share of the pairs of a
+// sharded run.  NB_FLAG_NO_SYMMETRY forces the one-sided kernels.
 static bool sym_eligible(const nb_sim *s)
 {
-    if (getenv("NB_NO_SYMMETRY")) return false;
+    if (s->p.flags & NB_FLAG_NO_SYMMETRY) return false;
     if (s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
     if (s->fp64 && s->p.rsqrt_mode != NB_RSQRT_EXACT) return false;
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
     if (s->n < 8 * (size_t)SYM_SB) return false;
-    const size_t tiles = (s->n + SYM_SB - 1) / SYM_SB;
-    const size_t world = s->p.shard_world > 1 ? (size_t)s->p.shard_world : 1;
-    const size_t rrows = world == 1 ? tiles : 2 * tiles / world + 2;            // travelling rows held by one handle
-    // travelling slabs: sized for the 288 GB of an MI355X — up to 48 GiB and a third of what is free now
-    // (N = 1 048 576: 4 GiB; N ~ 3.5 million fp32 is the largest symmetric run; beyond that the one-sided kernel)
-    // Ranks of a sharded run must all take the same decision (it selects the exchange protocol), so there the
-    // limit does not look at this device's free memory; an allocation that does not fit fails nb_create loudly.
-    size_t cap = (size_t)48 << 30;
+    const uint32_t world = s->p.shard_world > 1 ? (uint32_t)s->p.shard_world : 1u;
+    // Travelling partials: one element per (tile, later particle) pair the handle evaluates — tiles x n / 2 for a
+    // whole system (1 GiB at N = 524 288 fp32, 2 GiB at 1 048 576, 32 GiB at 4 194 304), 1/world of that for a rank.
+    // Sized for the 288 GB of an MI355X: up to 96 GiB and a third of what is free now (N ~ 7 million fp32 is the
+    // largest symmetric run; beyond that the one-sided kernel).  Ranks of a sharded run must all take the same
+    // decision (it selects the exchange protocol), so there the limit does not look at this device's free memory
+    // and uses the rank-independent bound; an allocation that does not fit fails nb_create loudly (NB_ENOMEM).
+    size_t cap = (size_t)96 << 30;
     if (world == 1) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)24 << 30; }
         if (free_b / 3 < cap) cap = free_b / 3;
     }
-    if (rrows * s->n * s->esz > cap) return false;
+    if (sym_slab_r_bound((uint32_t)s->n, world) * s->esz > cap) return false;
     return true;
 }
 
@@ -253,210 +226,67 @@ static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
            s->n % (w * SYM_SB) == 0 && s->i_count == s->n / w && s->i_begin == (size_t)s->p.shard_rank * s->i_count;   // equal blocks of whole tiles
 }
 
-// Pure planner of the symmetric scheme (no device calls; also behind nb_debug_sym_plan for the CPU tests).
-// The particle range is cut into `world` equal blocks (block r is integrated by rank r; blocks are whole
-// tiles).  Rank r evaluates
-//   LOCAL items  every unordered pair INSIDE its own block: the diagonal items of its tiles and the
-//                symmetric items whose chunks lie in the same block — they need only positions the rank
-//                has just produced itself, so they run while the all-gather of the other blocks is in flight;
-//   CROSS items  an equal share of the pairs between different blocks: the ordered list of all
-//                (tile I, L-chunk slice after I's block) items is cut into `world` runs of equal work.
-// Outputs: the items of `rank` (n_local local ones first), the first slab_s row of every tile (rowbase,
-// tiles + 1 entries; a tile's rows are its local items then its cross items) and the slab_r row segments
-// (row, particle range) the rank's items write.  Returns the chunks per item, L.
-//   LATE items   (world > 1) a small tail of the local items, held back until the cross items are done: they
-//                touch only the rank's own block, so they can run while the reduce-scatter of the partial
-//                accelerations is in flight, and are folded in by the integrate step.
-// Items come out as [local | cross | late] (SymItem::pad0 = 0 / 1 / 2); a tile's stationary rows are
-// [rowbase[g], rowmid[g]) for local + cross and [rowmid[g], rowbase[g+1]) for late; segs holds the
-// nsegs_main segments of local + cross first, then the late ones.
-struct SymPlan {
-    std::vector<SymItem> items;
-    uint32_t n_local = 0, n_cross = 0, n_late = 0, nsegs_main = 0, L = 0;
-    std::vector<uint32_t> rowbase, rowmid;
-    std::vector<SymSeg> segs;
-};
-
-static void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, uint32_t forced_L,
-                           uint32_t late_units, SymPlan &pl, uint32_t late_chunks = 2)
-{
-    const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
-    const uint32_t tpb = world > 1 ? (n / world) / SYM_SB : tiles;                 // tiles per block
-    auto block_end_chunk = [&](uint32_t I) {                                       // first chunk after I's block
-        const uint32_t e = (I / tpb + 1) * tpb * cpt;
-        return (world > 1 && e < chunks) ? e : chunks;
-    };
-    // work (in chunks) of this rank: its local pairs + 1/world of the cross pairs
-    uint64_t local = 0, cross_total = 0;
-    for (uint32_t I = 0; I < tiles; ++I) {
-        const uint32_t be = block_end_chunk(I);
-        if (I / tpb == rank || world == 1) local += be - I * cpt;                 // own chunks (diagonal) + later chunks of the block
-        cross_total += chunks - be;
-    }
-    // workgroups wanted (profiles/r01_*sweep.log): with the guided tail 24 per CU run as fast as 32 (L = 43-48 vs 33
-    // at N = 262 144) and write a quarter fewer slab rows
-    const uint32_t target = (world > 1 ? 16u : 24u) * cus;
-    // Chunks per item.  Large systems: as many items as fill the chip `target` workgroups deep.  Small ones
-    // (fewer chunk-units than that): one chunk per item would be the finest grain, but every item costs a
-    // 16-KiB slab row that sym_gather re-reads and a prologue, while coarse items cost tail — the optimum
-    // sits near items ~ 20 sqrt(units) at 256 CUs (profiles/r01_force_sym_small_n_sweep.log: L = 2 at
-    // N = 16 384, 3 at 25 000-32 768, 4-6 at 65 536, -5 ... -10 % step time against L = 1).
-    const uint64_t units = local + cross_total / world;
-    uint32_t L = forced_L;
-    if (!L) {
-        const uint32_t fill = (uint32_t)((units + target - 1) / target);
-        const uint32_t grain = (uint32_t)(sqrt((double)units) * 256.0 / (20.0 * (double)cus) + 0.5);
-        L = fill > grain ? fill : grain;
-    }
-    if (L < 1) L = 1;
-
-    // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
-    std::vector<SymItem> local_items, cross_items, late_items;
-    std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0), late_rows_of(tiles, 0);
-    uint64_t cum = 0;
-    for (uint32_t I = 0; I < tiles; ++I) {
-        const uint32_t be = block_end_chunk(I);
-        if (I / tpb == rank || world == 1) {
-            const uint32_t d0 = I * cpt, dend = (I + 1) * cpt < chunks ? (I + 1) * cpt : chunks;
-            for (uint32_t c = d0; c < dend; c += L) {                               // diagonal, one-sided
-                local_items.push_back(SymItem{I, c, dend - c < L ? dend - c : L, 0u, 0u, 1u, 0u, 0u});
-                ++local_rows_of[I];
-            }
-            for (uint32_t c = dend; c < be; c += L) {                               // rest of the block, symmetric
-                local_items.push_back(SymItem{I, c, be - c < L ? be - c : L, 0u, 0u, 0u, 0u, 0u});
-                ++local_rows_of[I];
-            }
-        }
-        for (uint32_t c = be; c < chunks; c += L) {                                 // later blocks
-            const uint32_t cnt = chunks - c < L ? chunks - c : L;
-            const uint32_t owner = cross_total ? (uint32_t)((cum * world) / cross_total) : 0u;
-            if (owner == rank) {
-                cross_items.push_back(SymItem{I, c, cnt, 0u, 0u, 0u, 0u, 0u});
-                ++cross_rows_of[I];
-            }
-            cum += cnt;
-        }
-    }
-    // Late items: whole items off the end of the local list, at most late_units chunk-units and at most half
-    // of the local work, re-cut into 2-chunk items (1 in fp64; they run alone on the chip: fine grain, short tail).
-    if (world > 1 && late_units > 0) {
-        const uint64_t budget = late_units < local / 2 ? late_units : local / 2;
-        uint64_t taken = 0;
-        std::vector<SymItem> held;
-        while (!local_items.empty() && taken + local_items.back().cnt <= budget) {
-            taken += local_items.back().cnt;
-            --local_rows_of[local_items.back().tile];
-            held.push_back(local_items.back());
-            local_items.pop_back();
-        }
-        for (auto it = held.rbegin(); it != held.rend(); ++it)
-            for (uint32_t c = 0; c < it->cnt; c += late_chunks) {
-                SymItem q = *it;
-                q.c0 = it->c0 + c; q.cnt = it->cnt - c < late_chunks ? it->cnt - c : late_chunks;
-                late_items.push_back(q);
-                ++late_rows_of[q.tile];
-            }
-    }
-    // Guided tail: workgroups are dispatched in item order and an item is a fixed amount of VALU work, so a
-    // launch ends with up to one item time of partly idle CUs (half of it on average: 3 % of a single-GPU step,
-    // 7 % of a rank's step at world = 8).  The end of each launch's work is cut into finer items
-    // (L/2, L/4, L/8 chunks from 85 %, 94 %, 98 % of the work on; profiles/r01_guided_tail_ab.log): -2 % step time.
-    // Splitting happens after the cross runs were assigned, so every rank still sees the same run boundaries.
-    if (!getenv("NB_SYM_NO_GUIDED_TAIL")) {
-        double tail_at[3] = {0.85, 0.94, 0.98};                                      // NB_SYM_TAIL="a,b,c" overrides (tools/guided_tail_ab.py)
-        if (const char *e = getenv("NB_SYM_TAIL")) (void)sscanf(e, "%lf,%lf,%lf", &tail_at[0], &tail_at[1], &tail_at[2]);
-        auto guided = [&](std::vector<SymItem> &list, std::vector<uint32_t> &rows_of) {
-            uint64_t total = 0, done = 0;
-            for (const auto &it : list) total += it.cnt;
-            std::vector<SymItem> out;
-            out.reserve(list.size() * 2);
-            for (const auto &it : list) {
-                const double f = total ? (double)done / (double)total : 0.0;
-                const uint32_t div = f < tail_at[0] ? 1u : f < tail_at[1] ? 2u : f < tail_at[2] ? 4u : 8u;
-                const uint32_t piece = (L + div - 1) / div;
-                done += it.cnt;
-                if (div == 1 || it.cnt <= piece) { out.push_back(it); continue; }
-                --rows_of[it.tile];
-                for (uint32_t c = 0; c < it.cnt; c += piece) {
-                    SymItem q = it;
-                    q.c0 = it.c0 + c; q.cnt = it.cnt - c < piece ? it.cnt - c : piece;
-                    out.push_back(q);
-                    ++rows_of[it.tile];
-                }
-            }
-            list.swap(out);
-        };
-        guided(local_items, local_rows_of);
-        guided(cross_items, cross_rows_of);
-    }
-    // slab rows: a tile's stationary rows are contiguous (local, cross, then late items); one travelling
-    // row per (tile, group) with the particle range the group's symmetric items cover
-    auto span_of = [&](const std::vector<SymItem> &list, std::vector<uint32_t> &lo, std::vector<uint32_t> &hi) {
-        lo.assign(tiles, 0xffffffffu); hi.assign(tiles, 0);
-        for (const auto &it : list) {
-            if (it.diag) continue;
-            if (it.c0 < lo[it.tile]) lo[it.tile] = it.c0;
-            if (it.c0 + it.cnt > hi[it.tile]) hi[it.tile] = it.c0 + it.cnt;
-        }
-    };
-    std::vector<uint32_t> llo, lhi, clo, chi, tlo, thi;
-    span_of(local_items, llo, lhi); span_of(cross_items, clo, chi); span_of(late_items, tlo, thi);
-    pl.rowbase.assign(tiles + 1, 0);
-    pl.rowmid.assign(tiles, 0);
-    pl.segs.clear();
-    std::vector<uint32_t> next_local(tiles), next_cross(tiles), next_late(tiles), seg_local(tiles, 0), seg_cross(tiles, 0), seg_late(tiles, 0);
-    uint32_t row = 0, rrow = 0;
-    auto up = [](uint32_t v, uint32_t cap) { return v < cap ? v : cap; };
-    for (uint32_t I = 0; I < tiles; ++I) {
-        pl.rowbase[I] = row;
-        next_local[I] = row; row += local_rows_of[I];
-        next_cross[I] = row; row += cross_rows_of[I];
-        pl.rowmid[I] = row;
-        next_late[I] = row; row += late_rows_of[I];
-        if (lhi[I] > llo[I]) { seg_local[I] = rrow; pl.segs.push_back(SymSeg{rrow++, llo[I] * SYM_CH, up(lhi[I] * SYM_CH, n), I}); }
-        if (chi[I] > clo[I]) { seg_cross[I] = rrow; pl.segs.push_back(SymSeg{rrow++, clo[I] * SYM_CH, up(chi[I] * SYM_CH, n), I}); }
-    }
-    pl.rowbase[tiles] = row;
-    pl.nsegs_main = (uint32_t)pl.segs.size();
-    for (uint32_t I = 0; I < tiles; ++I)
-        if (thi[I] > tlo[I]) { seg_late[I] = rrow; pl.segs.push_back(SymSeg{rrow++, tlo[I] * SYM_CH, up(thi[I] * SYM_CH, n), I}); }
-    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_row = seg_local[it.tile]; it.pad0 = 0u; }
-    for (auto &it : cross_items) { it.s_row = next_cross[it.tile]++; it.r_row = seg_cross[it.tile]; it.pad0 = 1u; }
-    for (auto &it : late_items)  { it.s_row = next_late[it.tile]++;  it.r_row = seg_late[it.tile];  it.pad0 = 2u; }
-    pl.n_local = (uint32_t)local_items.size();
-    pl.n_cross = (uint32_t)cross_items.size();
-    pl.n_late = (uint32_t)late_items.size();
-    pl.items = std::move(local_items);
-    pl.items.insert(pl.items.end(), cross_items.begin(), cross_items.end());
-    pl.items.insert(pl.items.end(), late_items.begin(), late_items.end());
-    pl.L = L;
-}
-
 // Chunk-units of local work a rank holds back to run beside the reduce-scatter: 40 us of whole-chip work at the
 // measured 35 units/us (fp32) or 14 (fp64) of 256 CUs.  Alone on the chip those items take 50-60 us and the
 // hand-over between the streams ~15 us, so the split pays when the collective is exposed for longer than that
 // share of a step: from 8 ranks on (a rank's step at N = 262 144 is ~1 ms there; at 2-4 ranks it measured
-// neutral to -2 %, profiles/r01_late_items_ab.log).  NB_SYM_LATE_US=<us> forces it for any world size, 0 disables.
-static uint32_t late_units_for(bool fp64, int cus, uint32_t world)
+// neutral to -2 %, profiles/r01_late_items_ab.log).  nb_params.sym_late_us > 0 forces it for any world size,
+// < 0 disables it.
+static uint32_t late_units_for(const nb_params &p, bool fp64, int cus, uint32_t world)
 {
-    const char *e = getenv("NB_SYM_LATE_US");
-    const double us = e ? atof(e) : (world >= 8 ? 40.0 : 0.0);
+    const double us = p.sym_late_us > 0.0f ? (double)p.sym_late_us : p.sym_late_us < 0.0f ? 0.0 : (world >= 8 ? 40.0 : 0.0);
     if (!(us > 0.0)) return 0;
     return (uint32_t)(us * (fp64 ? 14.0 : 35.0) * (double)cus / 256.0);
 }
 
-// CPU-testable view of the planner: fills up to cap items (8 uint32 each: tile, c0, cnt, s_row, r_row, diag,
-// group (0 local, 1 cross, 2 late), 0); the first *n_local of them are the rank's (early) local items.
-extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, uint32_t *items_out, size_t cap,
-                                 uint32_t *n_items, uint32_t *n_local, uint32_t *chunks_per_item)
+static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t world, bool sharded)
 {
+    SymTuning t;
+    t.forced_L = p.sym_chunks_per_item > 0 ? (uint32_t)p.sym_chunks_per_item : 0u;
+    t.late_units = sharded ? late_units_for(p, fp64, cus, world) : 0u;
+    t.late_chunks = fp64 ? 1u : 2u;
+    t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
+    if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
+        for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k];
+    return t;
+}
+
+static void fill_sym_info(const SymPlan &pl, uint32_t n, uint32_t world, int cus, size_t esz, bool enabled, nb_sym_info *out)
+{
+    const uint32_t sz = out->struct_size;
+    memset(out, 0, sizeof *out);
+    out->struct_size = sz;
+    out->enabled = enabled ? 1 : 0;
+    out->chunks_per_item = pl.L;
+    out->items = (uint32_t)pl.items.size();
+    out->items_local = pl.n_local; out->items_cross = pl.n_cross; out->items_late = pl.n_late;
+    out->tiles = pl.tiles;
+    out->rows_s = pl.rowbase.empty() ? 0u : pl.rowbase[pl.tiles];
+    out->segments = (uint32_t)pl.segs.size();
+    out->cus = (uint32_t)cus;
+    out->units_local = pl.units_local; out->units_cross = pl.units_cross; out->units_late = pl.units_late;
+    sym_units(n, world, nullptr, &out->cross_units_total);
+    out->slab_s_bytes = (uint64_t)out->rows_s * SYM_SB * esz;
+    out->slab_r_bytes = pl.slab_r_elems * esz;
+    out->coverage_entries = pl.cov_main.size() + pl.cov_late.size();
+}
+
+// CPU-testable view of the planner (no device call).
+extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
+                                 nb_sym_item *items_out, size_t cap, nb_sym_info *info)
+{
+    static_assert(sizeof(nb_sym_item) == sizeof(SymItem) && offsetof(nb_sym_item, r_base) == offsetof(SymItem, r_base) &&
+                  offsetof(nb_sym_item, group) == offsetof(SymItem, group), "nb_sym_item mirrors SymItem");
     if (n == 0 || n > 0x7fffff00u || cus < 1 || world < 1 || rank < 0 || rank >= world ||
-        (world > 1 && (n % ((size_t)world * SYM_SB)) != 0)) { nb_set_error("nb_debug_sym_plan: bad arguments"); return NB_EINVAL; }
+        (world > 1 && (n % ((size_t)world * SYM_SB)) != 0)) return nb_fail(NB_EINVAL, "nb_debug_sym_plan: bad arguments");
+    if (tuning && tuning->struct_size != sizeof(nb_params)) return nb_fail(NB_EINVAL, "nb_debug_sym_plan: tuning->struct_size");
+    if (info && info->struct_size != sizeof(nb_sym_info)) return nb_fail(NB_EINVAL, "nb_debug_sym_plan: info->struct_size");
+    nb_params p;
+    if (tuning) p = *tuning; else nb_params_default(&p);
+    const bool fp64 = p.precision == NB_FP64;
     SymPlan pl;
-    build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, 0, late_units_for(false, cus, (uint32_t)world), pl);
-    if (n_items) *n_items = (uint32_t)pl.items.size();
-    if (n_local) *n_local = pl.n_local;
-    if (chunks_per_item) *chunks_per_item = pl.L;
+    build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, tuning_of(p, fp64, cus, (uint32_t)world, world > 1), pl);
+    if (info) fill_sym_info(pl, (uint32_t)n, (uint32_t)world, cus, fp64 ? 16 : 8, true, info);
     if (items_out) memcpy(items_out, pl.items.data(), (pl.items.size() < cap ? pl.items.size() : cap) * sizeof(SymItem));
     return NB_OK;
 }
@@ -466,32 +296,37 @@ static int plan_sym(nb_sim *s)
     const uint32_t n = (uint32_t)s->n;
     const uint32_t world = s->sym_sharded ? (uint32_t)s->p.shard_world : 1u;
     const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
-    const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB;
-    const char *envl = getenv("NB_SYM_L");
     SymPlan pl;
-    build_sym_plan(n, (uint32_t)s->cus, rank, world, envl && atoi(envl) > 0 ? (uint32_t)atoi(envl) : 0u,
-                   s->sym_sharded ? late_units_for(s->fp64, s->cus, world) : 0u, pl, s->fp64 ? 1u : 2u);
-    const uint32_t row = pl.rowbase[tiles], rrow = (uint32_t)pl.segs.size();
+    build_sym_plan(n, (uint32_t)s->cus, rank, world, tuning_of(s->p, s->fp64, s->cus, world, s->sym_sharded), pl);
+    const uint32_t tiles = pl.tiles, row = pl.rowbase[tiles];
+    s->sym_info.struct_size = (uint32_t)sizeof(nb_sym_info);
+    fill_sym_info(pl, n, world, s->cus, s->esz, true, &s->sym_info);
     s->sym_items_local = pl.n_local; s->sym_items_cross = pl.n_cross; s->sym_items_late = pl.n_late;
-    s->sym_nsegs = pl.nsegs_main; s->sym_nsegs_late = rrow - pl.nsegs_main;
     s->sym_items = (uint32_t)pl.items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = pl.L;
     // row bounds for the gathers: [lo | mid | hi] = rowbase[0..tiles), rowmid[0..tiles), rowbase[1..tiles]
     std::vector<uint32_t> bounds(3 * (size_t)tiles);
     for (uint32_t g = 0; g < tiles; ++g) { bounds[g] = pl.rowbase[g]; bounds[tiles + g] = pl.rowmid[g]; bounds[2 * (size_t)tiles + g] = pl.rowbase[g + 1]; }
+    // coverage lists of the main and the late gather: [begin_main (tiles + 1) | begin_late (tiles + 1)], entries of both back to back
+    std::vector<uint32_t> cbegin(pl.cov_main_begin);
+    cbegin.insert(cbegin.end(), pl.cov_late_begin.begin(), pl.cov_late_begin.end());
+    std::vector<SymCov> cov(pl.cov_main);
+    cov.insert(cov.end(), pl.cov_late.begin(), pl.cov_late.end());
+    s->sym_cov_late_off = (uint32_t)pl.cov_main.size();
     HIPCHK(hipMalloc((void **)&s->sym_items_dev, pl.items.size() * sizeof(SymItem)));
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, bounds.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&s->sym_segs_dev, (pl.segs.size() ? pl.segs.size() : 1) * sizeof(SymSeg)));
+    HIPCHK(hipMalloc((void **)&s->sym_cov_begin_dev, cbegin.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&s->sym_cov_dev, (cov.size() ? cov.size() : 1) * sizeof(SymCov)));
     HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
-    HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(rrow ? rrow : 1) * n * s->esz));
+    HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(pl.slab_r_elems ? pl.slab_r_elems : 1) * s->esz));
     HIPCHK(hipMemcpy(s->sym_items_dev, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->sym_rowbase_dev, bounds.data(), bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_segs_dev, pl.segs.data(), pl.segs.size() * sizeof(SymSeg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->sym_cov_begin_dev, cbegin.data(), cbegin.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!cov.empty()) HIPCHK(hipMemcpy(s->sym_cov_dev, cov.data(), cov.size() * sizeof(SymCov), hipMemcpyHostToDevice));
     // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
     // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
     // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
-    // same trick costs 4 % — profiles/r01_aux_stream_ab.log — hence the bound).  NB_SYM_AUX_STREAM=0/1 forces it.
-    const char *auxenv = getenv("NB_SYM_AUX_STREAM");
-    s->aux_local = s->sym_sharded && (auxenv ? atoi(auxenv) != 0 : s->sym_items_local <= 4u * (uint32_t)s->cus);
+    // same trick costs 4 % — profiles/r01_aux_stream_ab.log — hence the bound).  nb_params.sym_aux_stream = 1 / -1 forces it.
+    s->aux_local = s->sym_sharded && (s->p.sym_aux_stream ? s->p.sym_aux_stream > 0 : s->sym_items_local <= 4u * (uint32_t)s->cus);
     if (s->aux_local || s->sym_items_late) {         // the late items always run on the side stream
         HIPCHK(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -519,7 +354,7 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->mass); (void)hipFree(s->radius);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
     (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
-    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_segs_dev);
+    (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
     if (s->staging) (void)hipHostFree(s->staging);
@@ -535,7 +370,7 @@ static int do_upload(nb_sim *s, const nb_body *in)
 {
     // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
     // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_NO_UNIFORM_MASS=1 disables it.
-    s->uniform_mass = s->n > 0 && !getenv("NB_NO_UNIFORM_MASS") && s->p.sum_order == NB_SUM_TILED;
+    s->uniform_mass = s->n > 0 && !(s->p.flags & NB_FLAG_NO_UNIFORM_MASS) && s->p.sum_order == NB_SUM_TILED;
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
@@ -597,13 +432,13 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (p.shard_world < 0 || (p.shard_world > 1 && (p.shard_rank < 0 || p.shard_rank >= p.shard_world))) { nb_set_error("nb_create: bad shard_rank/shard_world %d/%d", p.shard_rank, p.shard_world); return nullptr; }
 
     int ndev = nb_device_count();
-    if (ndev <= 0) { nb_set_error("nb_create: no HIP device visible (this library has no CPU path)"); return nullptr; }
+    if (ndev <= 0) { nb_fail(NB_ENODEVICE, "nb_create: no HIP device visible (this library has no CPU path)"); return nullptr; }
     int dev = p.device;
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { nb_set_error("nb_create: device %d out of range (%d visible)", dev, ndev); return nullptr; }
 
     nb_sim *s = new (std::nothrow) nb_sim;
-    if (!s) { nb_set_error("nb_create: out of host memory"); return nullptr; }
+    if (!s) { nb_fail(NB_ENOMEM, "nb_create: out of host memory"); return nullptr; }
     s->p = p; s->n = n; s->i_begin = (size_t)p.i_begin; s->i_count = (size_t)p.i_count; s->dev = dev;
     s->fp64 = p.precision == NB_FP64;
     s->rsz = s->fp64 ? 8 : 4;
@@ -611,8 +446,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->esz = s->dims3 ? sizeof(float4) : 2 * s->rsz;
 
     auto fail = [&](const char *what, hipError_t e) -> nb_sim * {
-        nb_set_error("nb_create: %s: %s", what, hipGetErrorString(e));
         free_all(s);
+        nb_fail(hip_code(e), "nb_create: %s: %s", what, hipGetErrorString(e));
         return nullptr;
     };
     hipError_t e;
@@ -652,7 +487,7 @@ extern "C" void nb_destroy(nb_sim *s) { free_all(s); }
 
 extern "C" int nb_upload(nb_sim *s, const nb_body *in)
 {
-    if (!s || !in) { nb_set_error("nb_upload: NULL argument"); return NB_EINVAL; }
+    if (!s || !in) return nb_fail(NB_EINVAL, "nb_upload: NULL argument");
     if (bind(s)) return NB_EHIP;
     return do_upload(s, in);
 }
@@ -783,33 +618,34 @@ static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
     const uint32_t n = (uint32_t)s->n, gg = (n + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
     void *dst = s->sym_sharded ? s->acc_full : s->partial;
     const uint32_t *lo = s->sym_rowbase_dev, *hi = s->sym_rowbase_dev + tiles;      // [first row, first late row)
+    const uint32_t *cb = s->sym_cov_begin_dev;                                      // coverage lists of the main gather
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
     if (s->dims3) {
         const float4 *ss = (const float4 *)s->sym_slab_s, *sr = (const float4 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, (float4 *)dst,
                                                            (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
                                                            (float)dt, (float)dt, kd);
         else
-            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, (float4 *)dst,
+            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, (float4 *)dst,
                                                             nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0);
     } else if (s->fp64) {
         const double2 *ss = (const double2 *)s->sym_slab_s, *sr = (const double2 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (double2 *)dst, nullptr,
+            sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double2 *)dst, nullptr,
                                                                   (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
                                                                   dt, dt, s->p.extras, kd);
         else
-            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (double2 *)dst, nullptr,
+            sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double2 *)dst, nullptr,
                                                                    nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
     } else {
         const float2 *ss = (const float2 *)s->sym_slab_s, *sr = (const float2 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (float2 *)dst, nullptr,
+            sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float2 *)dst, nullptr,
                                                                  (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
                                                                  (float)dt, (float)dt, s->p.extras, kd);
         else
-            sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, s->sym_segs_dev, s->sym_nsegs, n, 0u, n, (float2 *)dst, nullptr,
+            sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float2 *)dst, nullptr,
                                                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
     }
     HIPCHK(hipGetLastError());
@@ -823,16 +659,17 @@ static int launch_sym_gather_late(nb_sim *s, double dt)
     const uint32_t n = (uint32_t)s->n, ic = (uint32_t)s->i_count, ib = (uint32_t)s->i_begin;
     const uint32_t gg = (ic + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
     const uint32_t *lo = s->sym_rowbase_dev + tiles, *hi = s->sym_rowbase_dev + 2 * (size_t)tiles;   // [first late row, end row)
-    const SymSeg *segs = s->sym_segs_dev + s->sym_nsegs;
+    const uint32_t *cb = s->sym_cov_begin_dev + (tiles + 1);                        // coverage lists of the late segments
+    const SymCov *cov = s->sym_cov_dev + s->sym_cov_late_off;
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
     if (s->fp64)
-        sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, lo, hi, segs,
-                                                              s->sym_nsegs_late, n, ib, ic, nullptr, (const double2 *)s->acc_owned,
+        sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, lo, hi, cb, cov,
+                                                              n, ib, ic, nullptr, (const double2 *)s->acc_owned,
                                                               (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
                                                               dt, dt, s->p.extras, kd);
     else
-        sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>((const float2 *)s->sym_slab_s, (const float2 *)s->sym_slab_r, lo, hi, segs,
-                                                             s->sym_nsegs_late, n, ib, ic, nullptr, (const float2 *)s->acc_owned,
+        sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>((const float2 *)s->sym_slab_s, (const float2 *)s->sym_slab_r, lo, hi, cb, cov,
+                                                             n, ib, ic, nullptr, (const float2 *)s->acc_owned,
                                                              (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
                                                              (float)dt, (float)dt, s->p.extras, kd);
     HIPCHK(hipGetLastError());
@@ -942,9 +779,9 @@ static bool two_phase(const nb_sim *s) { return sharded(s) && s->p.sum_order != 
 
 extern "C" int nb_step_begin(nb_sim *s, float dt)
 {
-    if (!s) { nb_set_error("nb_step_begin: NULL handle"); return NB_EINVAL; }
-    if (s->in_step) { nb_set_error("nb_step_begin: previous step not finished"); return NB_ESTATE; }
-    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) { nb_set_error("sharded stepping supports the kick-drift integrator only"); return NB_EINVAL; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_step_begin: NULL handle");
+    if (s->in_step) return nb_fail(NB_ESTATE, "nb_step_begin: previous step not finished");
+    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) return nb_fail(NB_EINVAL, "sharded stepping supports the kick-drift integrator only");
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     s->in_step = true;
@@ -966,10 +803,10 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
 
 extern "C" int nb_step_mid(nb_sim *s)
 {
-    if (!s) { nb_set_error("nb_step_mid: NULL handle"); return NB_EINVAL; }
-    if (!s->in_step) { nb_set_error("nb_step_mid: no step in flight"); return NB_ESTATE; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_step_mid: NULL handle");
+    if (!s->in_step) return nb_fail(NB_ESTATE, "nb_step_mid: no step in flight");
     if (!s->sym_sharded) return NB_OK;                 // nothing between begin and finish in the other protocols
-    if (s->mid_done) { nb_set_error("nb_step_mid: already called for this step"); return NB_ESTATE; }
+    if (s->mid_done) return nb_fail(NB_ESTATE, "nb_step_mid: already called for this step");
     if (bind(s)) return NB_EHIP;
     int rc = launch_sym_items(s, s->sym_items_local, s->sym_items_cross);   // cross-block pairs: need the gathered positions
     if (rc) return rc;
@@ -988,14 +825,14 @@ extern "C" int nb_step_mid(nb_sim *s)
 
 extern "C" int nb_step_finish(nb_sim *s)
 {
-    if (!s) { nb_set_error("nb_step_finish: NULL handle"); return NB_EINVAL; }
-    if (!s->in_step) { nb_set_error("nb_step_finish: no step in flight"); return NB_ESTATE; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_step_finish: NULL handle");
+    if (!s->in_step) return nb_fail(NB_ESTATE, "nb_step_finish: no step in flight");
     if (bind(s)) return NB_EHIP;
     s->in_step = false;
     int rc;
     uint32_t nslabs;
     if (s->sym_sharded) {
-        if (!s->mid_done) { s->in_step = true; nb_set_error("nb_step_finish: symmetric sharded handle needs nb_step_mid (and the reduce-scatter) first"); return NB_ESTATE; }
+        if (!s->mid_done) { s->in_step = true; return nb_fail(NB_ESTATE, "nb_step_finish: symmetric sharded handle needs nb_step_mid (and the reduce-scatter) first"); }
         s->mid_done = false;
         // the host has reduce-scattered acc_full into acc_owned: it is the one slab of the owned block
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
@@ -1062,10 +899,10 @@ static int step_kdk(nb_sim *s, double dt)
 
 extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
 {
-    if (!s) { nb_set_error("nb_step: NULL handle"); return NB_EINVAL; }
-    if (nsteps < 0) { nb_set_error("nb_step: nsteps < 0"); return NB_EINVAL; }
-    if (sharded(s)) { nb_set_error("nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish"); return NB_ESTATE; }
-    if (s->in_step) { nb_set_error("nb_step: a split step is in flight"); return NB_ESTATE; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_step: NULL handle");
+    if (nsteps < 0) return nb_fail(NB_EINVAL, "nb_step: nsteps < 0");
+    if (sharded(s)) return nb_fail(NB_ESTATE, "nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish");
+    if (s->in_step) return nb_fail(NB_ESTATE, "nb_step: a split step is in flight");
     if (bind(s)) return NB_EHIP;
     const float h = dt > 0.0f ? dt : s->p.dt;
     for (int k = 0; k < nsteps; ++k) {
@@ -1081,8 +918,8 @@ extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
 
 extern "C" int nb_accelerations(nb_sim *s)
 {
-    if (!s) { nb_set_error("nb_accelerations: NULL handle"); return NB_EINVAL; }
-    if (s->in_step) { nb_set_error("nb_accelerations: a split step is in flight"); return NB_ESTATE; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_accelerations: NULL handle");
+    if (s->in_step) return nb_fail(NB_ESTATE, "nb_accelerations: a split step is in flight");
     if (bind(s)) return NB_EHIP;
     int rc;
     if ((rc = launch_force(s, s->job_all))) return rc;
@@ -1091,7 +928,7 @@ extern "C" int nb_accelerations(nb_sim *s)
 
 extern "C" int nb_wait(nb_sim *s)
 {
-    if (!s) { nb_set_error("nb_wait: NULL handle"); return NB_EINVAL; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_wait: NULL handle");
     if (bind(s)) return NB_EHIP;
     if (s->aux) HIPCHK(hipStreamSynchronize(s->aux));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1118,21 +955,21 @@ static bool is_pinned_host(const void *p)
 
 extern "C" int nb_host_register(void *ptr, size_t bytes)
 {
-    if (!ptr || !bytes) { nb_set_error("nb_host_register: NULL argument"); return NB_EINVAL; }
+    if (!ptr || !bytes) return nb_fail(NB_EINVAL, "nb_host_register: NULL argument");
     HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return NB_OK;
 }
 
 extern "C" int nb_host_unregister(void *ptr)
 {
-    if (!ptr) { nb_set_error("nb_host_unregister: NULL argument"); return NB_EINVAL; }
+    if (!ptr) return nb_fail(NB_EINVAL, "nb_host_unregister: NULL argument");
     HIPCHK(hipHostUnregister(ptr));
     return NB_OK;
 }
 
 extern "C" int nb_sync(nb_sim *s, nb_body *out)
 {
-    if (!s || !out) { nb_set_error("nb_sync: NULL argument"); return NB_EINVAL; }
+    if (!s || !out) return nb_fail(NB_EINVAL, "nb_sync: NULL argument");
     if (bind(s)) return NB_EHIP;
     const bool direct = is_pinned_host(out);
     if (!direct && ensure_staging(s)) return NB_EHIP;
@@ -1155,8 +992,8 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
 
 extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
 {
-    if (!s || !out_xy) { nb_set_error("nb_sync_positions: NULL argument"); return NB_EINVAL; }
-    if (s->dims3) { nb_set_error("nb_sync_positions: 2-D handles only (use nb_sync for dims = 3)"); return NB_EINVAL; }
+    if (!s || !out_xy) return nb_fail(NB_EINVAL, "nb_sync_positions: NULL argument");
+    if (s->dims3) return nb_fail(NB_EINVAL, "nb_sync_positions: 2-D handles only (use nb_sync for dims = 3)");
     if (bind(s)) return NB_EHIP;
     if (ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
@@ -1175,7 +1012,7 @@ extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
 
 extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
 {
-    if (!s || !kinetic || !potential) { nb_set_error("nb_energy: NULL argument"); return NB_EINVAL; }
+    if (!s || !kinetic || !potential) return nb_fail(NB_EINVAL, "nb_energy: NULL argument");
     if (bind(s)) return NB_EHIP;
     const uint32_t g = (uint32_t)s->ered_blocks;
     const double eps2 = (double)s->p.eps * (double)s->p.eps;
@@ -1209,11 +1046,10 @@ extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which =
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
 extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
 {
-    if (!sims || count < 1) { nb_set_error("nb_exchange_positions: no handles"); return NB_EINVAL; }
+    if (!sims || count < 1) return nb_fail(NB_EINVAL, "nb_exchange_positions: no handles");
     for (int a = 0; a < count; ++a) {
         if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz) {
-            nb_set_error("nb_exchange_positions: handles must shard the same system");
-            return NB_EINVAL;
+            return nb_fail(NB_EINVAL, "nb_exchange_positions: handles must shard the same system");
         }
         if (bind(sims[a])) return NB_EHIP;
         HIPCHK(hipStreamSynchronize(sims[a]->stream));           // owner's new block is complete
@@ -1238,13 +1074,12 @@ extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
 
 extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
 {
-    if (!sims || count < 1 || count > 64) { nb_set_error("nb_exchange_accelerations: 1..64 handles"); return NB_EINVAL; }
+    if (!sims || count < 1 || count > 64) return nb_fail(NB_EINVAL, "nb_exchange_accelerations: 1..64 handles");
     PartialPtrs src;
     for (int a = 0; a < count; ++a) {
         if (!sims[a] || !sims[a]->sym_sharded || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz ||
             sims[a]->p.shard_world != count || sims[a]->p.shard_rank != a) {
-            nb_set_error("nb_exchange_accelerations: needs the `count` handles of one symmetric sharded run, in rank order");
-            return NB_EINVAL;
+            return nb_fail(NB_EINVAL, "nb_exchange_accelerations: needs the `count` handles of one symmetric sharded run, in rank order");
         }
         if (bind(sims[a])) return NB_EHIP;
         HIPCHK(hipStreamSynchronize(sims[a]->stream));           // its partial accelerations are complete
@@ -1280,8 +1115,8 @@ extern "C" void *nb_acc_buffer(nb_sim *s, int which)
 
 extern "C" int nb_dump(nb_sim *s, const char *path)
 {
-    if (!s || !path) { nb_set_error("nb_dump: NULL argument"); return NB_EINVAL; }
-    if (sharded(s)) { nb_set_error("nb_dump: sharded handle holds only its block; gather on the host and use nb_write_bodies"); return NB_ESTATE; }
+    if (!s || !path) return nb_fail(NB_EINVAL, "nb_dump: NULL argument");
+    if (sharded(s)) return nb_fail(NB_ESTATE, "nb_dump: sharded handle holds only its block; gather on the host and use nb_write_bodies");
     std::vector<nb_body> host(s->n);
     int rc = nb_sync(s, host.data());
     if (rc) return rc;
@@ -1293,14 +1128,14 @@ extern "C" int nb_dump(nb_sim *s, const char *path)
 // ---------------------------------------------------------------------------
 extern "C" int nb_profile_enable(nb_sim *s, int on)
 {
-    if (!s) { nb_set_error("nb_profile_enable: NULL handle"); return NB_EINVAL; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_profile_enable: NULL handle");
     s->prof = on != 0;
     return NB_OK;
 }
 
 extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *force_launches, int reset)
 {
-    if (!s) { nb_set_error("nb_profile_read: NULL handle"); return NB_EINVAL; }
+    if (!s) return nb_fail(NB_EINVAL, "nb_profile_read: NULL handle");
     if (bind(s)) return NB_EHIP;
     int rc = prof_collect(s);
     if (rc) return rc;
@@ -1310,19 +1145,29 @@ extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *forc
     return NB_OK;
 }
 
+extern "C" int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out)
+{
+    if (!s || !out) return nb_fail(NB_EINVAL, "nb_sym_plan_info: NULL argument");
+    if (out->struct_size != sizeof(nb_sym_info)) return nb_fail(NB_EINVAL, "nb_sym_plan_info: out->struct_size %u != %zu", out->struct_size, sizeof(nb_sym_info));
+    if (s->sym || s->sym_sharded) *out = s->sym_info;
+    else { memset(out, 0, sizeof *out); out->struct_size = (uint32_t)sizeof(nb_sym_info); out->cus = (uint32_t)s->cus; }
+    return NB_OK;
+}
+
 extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
 {
-    if (!s || !buf || !buflen) { nb_set_error("nb_describe: NULL argument"); return NB_EINVAL; }
+    if (!s || !buf || !buflen) return nb_fail(NB_EINVAL, "nb_describe: NULL argument");
     const ForceJob &a = s->job_all;
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u late=%u | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
-             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->sym_items_late, s->cus);
+             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->sym_items_late,
+             (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;
 }

@@ -6,14 +6,61 @@
  * ICs (Simulation::uniform_disc, Simulation.hpp:347-603, a Lorenz-attractor
  * trace) are restated in nb_default_ics.
  */
+#define _FILE_OFFSET_BITS 64
+#define _POSIX_C_SOURCE 200809L
 #include "nbody.h"
 #include "nb_internal.h"
 
 #include <errno.h>
 #include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* ---- errors: text and NB_E* code of the last failure on the calling thread ---- */
+static _Thread_local char g_err[512] = "";
+static _Thread_local int g_err_code = NB_OK;
+
+void nb_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    g_err_code = NB_EINVAL;
+}
+
+int nb_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    g_err_code = code;
+    return code;
+}
+
+void nb_clear_error(void) { g_err[0] = 0; g_err_code = NB_OK; }
+const char *nb_last_error(void) { return g_err; }
+int nb_last_error_code(void) { return g_err_code; }
+int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+void nb_params_default(nb_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->struct_size = (uint32_t)sizeof(nb_params);
+    p->eps = 1.0f;   /* Simulation.hpp:59  quadtree(1.0f, 1.0f, 16) */
+    p->dt = 0.01f;   /* main.cpp:39        SIMULATION_DT{0.01f} */
+    p->precision = NB_FP32;
+    p->rsqrt_mode = NB_RSQRT_EXACT;
+    p->sum_order = NB_SUM_TILED;
+    p->integrator = NB_INTEGRATOR_KICK_DRIFT;
+    p->extras = 0;
+    p->device = -1;
+    p->dims = 2;
+}
 
 /* ---- mt19937 (Matsumoto & Nishimura 1998), same stream as std::mt19937(seed),
  * which is the PRNG the reference seeds its ICs with (Simulation.hpp:349) ---- */
@@ -56,7 +103,7 @@ int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed) { return plummer(out, n
 
 static int plummer(nb_body *out, size_t n, uint32_t seed, int dims)
 {
-    if (!out && n) { nb_set_error("nb_plummer: out is NULL"); return NB_EINVAL; }
+    if (!out && n) return nb_fail(NB_EINVAL, "nb_plummer: out is NULL");
     nb_mt g;
     mt_seed(&g, seed);
     const double two_pi = 6.283185307179586476925286766559;
@@ -179,9 +226,9 @@ static void disc_sort(disc_key *v, size_t n)
 
 int nb_default_ics(nb_body *out, size_t n)
 {
-    if (!out && n) { nb_set_error("nb_default_ics: out is NULL"); return NB_EINVAL; }
+    if (!out && n) return nb_fail(NB_EINVAL, "nb_default_ics: out is NULL");
     if (n == 0) return NB_OK;
-    if (n > (1u << 24)) { nb_set_error("nb_default_ics: n = %zu too large", n); return NB_EINVAL; }
+    if (n > (1u << 24)) return nb_fail(NB_EINVAL, "nb_default_ics: n = %zu too large", n);
     static const float lo[3] = {0.00005f, 1.2f, 5.0f}, hi[3] = {0.8f, 2.5f, 50.0f}, weight[3] = {0.825f, 0.125f, 0.025f};
     float wsum = 0.0f, cum[3], run = 0.0f;
     for (int k = 0; k < 3; ++k) wsum += weight[k];
@@ -219,7 +266,7 @@ int nb_default_ics(nb_body *out, size_t n)
     }
     disc_key *order = (disc_key *)malloc(n * sizeof *order);
     nb_body *tmp = (nb_body *)malloc(n * sizeof *tmp);
-    if (!order || !tmp) { free(order); free(tmp); nb_set_error("nb_default_ics: out of memory"); return NB_ENOMEM; }
+    if (!order || !tmp) { free(order); free(tmp); return nb_fail(NB_ENOMEM, "nb_default_ics: out of memory"); }
     for (size_t i = 0; i < n; ++i) {
         const float x2 = out[i].pos.x * out[i].pos.x, y2 = out[i].pos.y * out[i].pos.y;
         order[i].key = x2 + y2;
@@ -253,7 +300,9 @@ typedef struct nb_file_header {
     int32_t  precision;
     int32_t  rsqrt_mode;
     int32_t  dims;          /* 0 or 2: planar (the reference); 3: z kept in the first padding float */
-    uint8_t  pad[12];
+    int32_t  sum_order;     /* the three fields below were zero padding in files written before they existed: */
+    int32_t  integrator;    /* 0 = the defaults (tiled sum, kick-drift, no extras), so old files read the same */
+    int32_t  extras;
 } nb_file_header;
 
 _Static_assert(sizeof(nb_file_header) == 64, "dump header is 64 bytes");
@@ -261,9 +310,9 @@ _Static_assert(sizeof(nb_file_header) == 64, "dump header is 64 bytes");
 int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t frame,
                     const nb_params *params)
 {
-    if (!path || (!bodies && n)) { nb_set_error("nb_write_bodies: NULL argument"); return NB_EINVAL; }
+    if (!path || (!bodies && n)) return nb_fail(NB_EINVAL, "nb_write_bodies: NULL argument");
     FILE *f = fopen(path, "wb");
-    if (!f) { nb_set_error("nb_write_bodies: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    if (!f) return nb_fail(NB_EIO, "nb_write_bodies: cannot open %s: %s", path, strerror(errno));
     nb_file_header h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, "NBODYAMD", 8);
@@ -275,6 +324,7 @@ int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t 
         h.eps = params->eps; h.dt = params->dt;
         h.precision = params->precision; h.rsqrt_mode = params->rsqrt_mode;
         h.dims = params->dims;
+        h.sum_order = params->sum_order; h.integrator = params->integrator; h.extras = params->extras;
     }
     const int keep_z = h.dims == 3;
     int rc = NB_OK;
@@ -282,7 +332,7 @@ int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t 
     /* records are written with padding forced to zero, whatever the caller holds */
     enum { CHUNK = 4096 };
     nb_body *buf = (nb_body *)malloc(sizeof(nb_body) * CHUNK);
-    if (!buf) { fclose(f); nb_set_error("nb_write_bodies: out of memory"); return NB_ENOMEM; }
+    if (!buf) { fclose(f); return nb_fail(NB_ENOMEM, "nb_write_bodies: out of memory"); }
     for (size_t base = 0; rc == NB_OK && base < n; base += CHUNK) {
         size_t c = n - base < CHUNK ? n - base : CHUNK;
         memset(buf, 0, sizeof(nb_body) * c);
@@ -298,26 +348,38 @@ int nb_write_bodies(const char *path, const nb_body *bodies, size_t n, uint64_t 
     }
     free(buf);
     if (fclose(f) != 0) rc = NB_EIO;
-    if (rc != NB_OK) nb_set_error("nb_write_bodies: short write to %s", path);
+    if (rc != NB_OK) nb_fail(rc, "nb_write_bodies: short write to %s", path);
     return rc;
 }
 
+/* The header is untrusted input: n must be a size the kernels can index and must match the file length
+ * exactly (64-byte header + n 64-byte records), so that no caller sizes a buffer from a forged count. */
 static int read_header(FILE *f, const char *path, nb_file_header *h)
 {
-    if (fread(h, sizeof *h, 1, f) != 1) { nb_set_error("%s: truncated header", path); return NB_EFORMAT; }
-    if (memcmp(h->magic, "NBODYAMD", 8) != 0) { nb_set_error("%s: bad magic", path); return NB_EFORMAT; }
-    if (h->version != 1 || h->body_size != sizeof(nb_body)) {
-        nb_set_error("%s: unsupported version %u / record size %u", path, h->version, h->body_size);
-        return NB_EFORMAT;
-    }
+    if (fread(h, sizeof *h, 1, f) != 1) return nb_fail(NB_EFORMAT, "%s: truncated header", path);
+    if (memcmp(h->magic, "NBODYAMD", 8) != 0) return nb_fail(NB_EFORMAT, "%s: bad magic", path);
+    if (h->version != 1 || h->body_size != sizeof(nb_body))
+        return nb_fail(NB_EFORMAT, "%s: unsupported version %u / record size %u", path, h->version, h->body_size);
+    if (h->n == 0 || h->n > 0x7fffff00u) return nb_fail(NB_EFORMAT, "%s: body count %llu out of range", path, (unsigned long long)h->n);
+    if (fseek(f, 0, SEEK_END) != 0) return nb_fail(NB_EIO, "%s: cannot seek", path);
+    const long long len = (long long)ftello(f);
+    if (len < 0 || (unsigned long long)len != sizeof *h + h->n * sizeof(nb_body))
+        return nb_fail(NB_EFORMAT, "%s: %lld bytes on disk, header promises %llu bodies (%llu bytes)", path, len,
+                       (unsigned long long)h->n, (unsigned long long)(sizeof *h + h->n * sizeof(nb_body)));
+    if (fseek(f, (long)sizeof *h, SEEK_SET) != 0) return nb_fail(NB_EIO, "%s: cannot seek", path);
+    if ((h->precision != NB_FP32 && h->precision != NB_FP64) || (h->rsqrt_mode != NB_RSQRT_EXACT && h->rsqrt_mode != NB_RSQRT_QUAKE) ||
+        (h->sum_order != NB_SUM_TILED && h->sum_order != NB_SUM_SEQUENTIAL) ||
+        (h->integrator != NB_INTEGRATOR_KICK_DRIFT && h->integrator != NB_INTEGRATOR_KDK) ||
+        (h->extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) || !(h->eps >= 0.0f))
+        return nb_fail(NB_EFORMAT, "%s: header holds parameters outside their enums", path);
     return NB_OK;
 }
 
 int nb_read_header(const char *path, size_t *n, uint64_t *frame, nb_params *params)
 {
-    if (!path) { nb_set_error("nb_read_header: NULL path"); return NB_EINVAL; }
+    if (!path) return nb_fail(NB_EINVAL, "nb_read_header: NULL path");
     FILE *f = fopen(path, "rb");
-    if (!f) { nb_set_error("nb_read_header: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    if (!f) return nb_fail(NB_EIO, "nb_read_header: cannot open %s: %s", path, strerror(errno));
     nb_file_header h;
     int rc = read_header(f, path, &h);
     fclose(f);
@@ -329,25 +391,22 @@ int nb_read_header(const char *path, size_t *n, uint64_t *frame, nb_params *para
         params->eps = h.eps; params->dt = h.dt;
         params->precision = h.precision; params->rsqrt_mode = h.rsqrt_mode;
         params->dims = h.dims == 3 ? 3 : 2;
+        params->sum_order = h.sum_order; params->integrator = h.integrator; params->extras = h.extras;
     }
     return NB_OK;
 }
 
 int nb_read_bodies(const char *path, nb_body *out, size_t n)
 {
-    if (!path || (!out && n)) { nb_set_error("nb_read_bodies: NULL argument"); return NB_EINVAL; }
+    if (!path || (!out && n)) return nb_fail(NB_EINVAL, "nb_read_bodies: NULL argument");
     FILE *f = fopen(path, "rb");
-    if (!f) { nb_set_error("nb_read_bodies: cannot open %s: %s", path, strerror(errno)); return NB_EIO; }
+    if (!f) return nb_fail(NB_EIO, "nb_read_bodies: cannot open %s: %s", path, strerror(errno));
     nb_file_header h;
     int rc = read_header(f, path, &h);
-    if (rc == NB_OK && (size_t)h.n != n) {
-        nb_set_error("%s: holds %llu bodies, caller asked for %zu", path, (unsigned long long)h.n, n);
-        rc = NB_EINVAL;
-    }
-    if (rc == NB_OK && fread(out, sizeof(nb_body), n, f) != n) {
-        nb_set_error("%s: truncated body records", path);
-        rc = NB_EFORMAT;
-    }
+    if (rc == NB_OK && (size_t)h.n != n)
+        rc = nb_fail(NB_EINVAL, "%s: holds %llu bodies, caller asked for %zu", path, (unsigned long long)h.n, n);
+    if (rc == NB_OK && fread(out, sizeof(nb_body), n, f) != n)
+        rc = nb_fail(NB_EFORMAT, "%s: truncated body records", path);
     fclose(f);
     return rc;
 }

@@ -8,8 +8,11 @@
 extern "C" {
 #endif
 
-/* printf-style setter for the thread-local text behind nb_last_error() */
+/* printf-style setters for the thread-local text / code behind nb_last_error() / nb_last_error_code():
+ * nb_set_error records NB_EINVAL (bad argument: by far the commonest cause), nb_fail the given code,
+ * which it also returns so that call sites read `return nb_fail(NB_EIO, ...)`. */
 void nb_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int  nb_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void nb_clear_error(void);
 
 #ifdef __cplusplus

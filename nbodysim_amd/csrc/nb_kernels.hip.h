@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nb_plan.h"   // SymItem, SymCov, SYM_SB, SYM_CH: shared with the host-side planner
+
 namespace nbk {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -360,16 +362,15 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 //                              LDS (wave order) and written once per chunk.
 // Outputs (all plain stores, summed later in a fixed order -> deterministic):
 //   slab_S[row][2048]   stationary partial of the item (row = item.s_row)
-//   slab_R[r][n]        travelling partials: the force of tile I (row r = item.r_row) on
-//                       particles after it
-// sym_gather adds, for particle k of tile g: its slab_S rows + slab_R[row(I)][k] for I < g.
+//   slab_R[r_base + j]  travelling partials: the force of tile I on particle j after it; only the
+//                       particle range a (tile, group)'s items really cover is stored (nb_plan.h)
+// sym_gather adds, for particle k of tile g: its slab_S rows + the slab_R entries of its tile's
+// coverage list (tiles I < g).
 // A rank of a sharded run holds only its share of the items (its own block's internal pairs plus
 // an equal run of the cross-block items); its gather then yields a PARTIAL acceleration for every
 // particle, and the ranks' partials are summed by the host's reduce-scatter.
 // Requires eps > 0 (r = 0 then contributes exactly 0); eps == 0 uses force_tiled_f32<GUARD>.
 // ---------------------------------------------------------------------------
-struct SymItem { uint32_t tile, c0, cnt, s_row, r_row, diag, pad0, pad1; };   // 32 bytes
-
 #ifndef NB_SYM_UNROLL
 #define NB_SYM_UNROLL 2      // rotation steps unrolled together (tools/sym_sweep.sh)
 #endif
@@ -382,8 +383,7 @@ struct SymItem { uint32_t tile, c0, cnt, s_row, r_row, diag, pad0, pad1; };   //
 constexpr int SYM_P = NB_SYM_P;                          // packed stationary pairs per lane
 constexpr int SYM_UNROLL = NB_SYM_UNROLL;
 constexpr uint32_t SYM_WT = 64 * 2 * SYM_P;              // stationary particles per wave  (512)
-constexpr uint32_t SYM_SB = 4 * SYM_WT;                  // ... per workgroup / block-tile (2048)
-constexpr uint32_t SYM_CH = 64;                          // travelling chunk
+static_assert(4 * SYM_WT == SYM_SB, "block-tile of the planner (nb_plan.h) = 4 waves x 64 lanes x 2 SYM_P particles");
 
 __device__ __forceinline__ float lane_rot(float v, int addr)
 {
@@ -505,7 +505,7 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
         xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; mi[p] = (v2f){m0, m1};
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
-    float2 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
+    float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
     if (diag) sym_chunks<RSQ, UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     else      sym_chunks<RSQ, UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
 
@@ -518,27 +518,28 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 }
 
 // acc_sum[k] = sum of particle k's stationary rows (its tile's items held here, in item order;
-//              none if rowbase[g] == rowbase[g+1])
-//            + sum over the travelling-row segments held here that cover k (in segment order).
-// One row of slab_r and the particle range [lo, hi) it holds valid travelling sums for.
-struct SymSeg { uint32_t row, lo, hi, tile; };
-
+//              none if row_lo[g] == row_hi[g])
+//            + sum over the coverage list of its tile (the travelling segments held here that meet the
+//              tile, in segment order) of the entries that cover k.
+//
 // 32 particles per workgroup, 8 threads per particle: thread (q, p) adds the rows r = q (mod 8)
 // of particle p's lists in ascending order, the 8 partials are then added in q order — a fixed
 // association whatever the launch, so results are reproducible run to run.
 constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
+static_assert(SYM_SB % GATHER_P == 0, "the particles of a gather workgroup share a tile");
 
 // FUSE: the summed acceleration goes straight into kick_drift_one (whole-system handles: the owned
 // block is everything; sharded ranks: the LATE local items' slabs on top of the reduce-scattered sum
 // `base`), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum (sharded ranks:
 // the partial of every particle, to be reduce-scattered).
-// The launch covers particles [k0, k0 + kn); tile g's stationary rows are [row_lo[g], row_hi[g]).
+// The launch covers particles [k0, k0 + kn); tile g's stationary rows are [row_lo[g], row_hi[g]), its
+// coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).
 template <typename real, bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
                 const typename vec2_of<real>::type *__restrict__ slab_r,
                 const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
-                const SymSeg *__restrict__ segs, uint32_t nsegs,
+                const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov,
                 uint32_t n, uint32_t k0, uint32_t kn,
                 typename vec2_of<real>::type *__restrict__ acc_sum,
                 const typename vec2_of<real>::type *__restrict__ base,
@@ -560,10 +561,11 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
             const real2 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y;
         }
-        for (uint32_t i = q; i < nsegs; i += GATHER_Q) {
-            const SymSeg sg = segs[i];
-            if (k < sg.lo || k >= sg.hi) continue;
-            const real2 b = slab_r[(size_t)sg.row * n + k];
+        const uint32_t c1 = cov_begin[g + 1];
+        for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
+            const SymCov cv = cov[i];
+            if (k < cv.lo || k >= cv.hi) continue;
+            const real2 b = slab_r[cv.base + (int64_t)k];
             a.x += b.x; a.y += b.y;
         }
     }
@@ -690,7 +692,7 @@ void force_sym_f64(const double2 *__restrict__ pos, const double *__restrict__ m
         if (g < n) { const double2 q = pos[g]; xi[p] = q.x; yi[p] = q.y; if constexpr (!UM) mi[p] = mass[g]; }
         ax[p] = 0.0; ay[p] = 0.0;
     }
-    double2 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
+    double2 *__restrict__ rrow = slab_r + it.r_base;
     if (it.diag) sym_chunks_f64<UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     else         sym_chunks_f64<UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     double2 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;

@@ -267,7 +267,7 @@ void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ 
         xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; zi[p] = (v2f){p0.z, p1.z}; mi[p] = (v2f){p0.w, p1.w};
         ax[p] = ay[p] = az[p] = (v2f){0.f, 0.f};
     }
-    float4 *__restrict__ rrow = slab_r + (size_t)it.r_row * n;
+    float4 *__restrict__ rrow = slab_r + it.r_base;
     if (it.diag) sym3_chunks<RSQ, UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
     else         sym3_chunks<RSQ, UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
     float4 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;
@@ -284,7 +284,7 @@ template <bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ slab_r,
                  const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
-                 const SymSeg *__restrict__ segs, uint32_t nsegs, uint32_t n,
+                 const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov, uint32_t n,
                  float4 *__restrict__ acc_sum, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
                  float4 *__restrict__ vel, float4 *__restrict__ acc, float dt_kick, float dt_drift, int flags)
 {
@@ -298,10 +298,11 @@ void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ s
             const float4 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
-        for (uint32_t i = q; i < nsegs; i += GATHER_Q) {
-            const SymSeg sg = segs[i];
-            if (k < sg.lo || k >= sg.hi) continue;
-            const float4 b = slab_r[(size_t)sg.row * n + k];
+        const uint32_t c1 = cov_begin[g + 1];
+        for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
+            const SymCov cv = cov[i];
+            if (k < cv.lo || k >= cv.hi) continue;
+            const float4 b = slab_r[cv.base + (int64_t)k];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
     }

@@ -51,7 +51,17 @@ class Simulation:
         shard_world: int = 0,
         acc_buffers: Optional[tuple] = None,
         dims: int = 2,
+        symmetry: bool = True,
+        uniform_mass: bool = True,
+        guided_tail: bool = True,
+        sym_chunks_per_item: int = 0,
+        sym_aux_stream: int = 0,
+        sym_late_us: float = 0.0,
+        lanes_p: int = 0,
+        sym_tail: Optional[tuple] = None,
     ):
+        """The last eight arguments are ``nb_params.flags`` and the launch-geometry tuning fields
+        (0 / True = the library's automatic choice); the library reads no environment variables."""
         lib = L.load()
         if bodies.dtype not in (L.BODY_DTYPE, L.BODY3_DTYPE):
             raise TypeError("bodies must be a numpy array of nbodysim_amd.BODY_DTYPE (64-byte Body records)")
@@ -75,6 +85,11 @@ class Simulation:
         if pos_buffers is not None:
             p.pos_buffers[0], p.pos_buffers[1] = pos_buffers
         p.dims = dims
+        p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
+                   | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL))
+        p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
+        if sym_tail is not None:
+            p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail
         p.shard_rank, p.shard_world = shard_rank, shard_world
         if acc_buffers is not None:
             p.acc_buffers[0], p.acc_buffers[1] = acc_buffers
@@ -82,7 +97,7 @@ class Simulation:
         self._params = p
         self._h = lib.nb_create(bodies.ctypes.data, bodies.shape[0], C.byref(p))
         if not self._h:
-            raise L.NBodyError("nb_create", L.NB_EHIP, L.last_error())
+            raise L.NBodyError("nb_create", L.last_error_code(), L.last_error())
         self.n = int(lib.nb_count(self._h))
         self.i_begin = int(lib.nb_owned_begin(self._h))
         self.i_count = int(lib.nb_owned_count(self._h))
@@ -166,6 +181,13 @@ class Simulation:
         ms, cnt = C.c_double(), C.c_uint64()
         L.check("nb_profile_read", self._lib.nb_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)))
         return ms.value, int(cnt.value)
+
+    def sym_info(self) -> dict:
+        """Figures of the symmetric work plan (``nb_sym_plan_info``): items, chunks per item, slab bytes ..."""
+        info = L.nb_sym_info()
+        info.struct_size = C.sizeof(L.nb_sym_info)
+        L.check("nb_sym_plan_info", self._lib.nb_sym_plan_info(self._h, C.byref(info)))
+        return info.as_dict()
 
     def describe(self) -> str:
         buf = C.create_string_buffer(512)

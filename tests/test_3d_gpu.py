@@ -59,14 +59,10 @@ def test_3d_with_planar_data_reproduces_the_2d_path():
 def test_3d_symmetric_equals_one_sided_and_momentum_is_conserved():
     ic = nb.plummer_3d(30000, 2).view(nb.BODY3_DTYPE)
     res = {}
-    for tag, env in (("sym", None), ("one_sided", "1")):
-        if env:
-            os.environ["NB_NO_SYMMETRY"] = env
-        try:
-            with nb.Simulation(ic, eps=0.02, dims=3) as sim:
-                res[tag] = sim.accelerations().astype(np.float64)
-        finally:
-            os.environ.pop("NB_NO_SYMMETRY", None)
+    for tag, symm in (("sym", True), ("one_sided", False)):
+        with nb.Simulation(ic, eps=0.02, dims=3, symmetry=symm) as sim:
+            assert f"symmetric={int(symm)}" in sim.describe()
+            res[tag] = sim.accelerations().astype(np.float64)
     scale = np.max(np.abs(res["one_sided"]))
     assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
     m = ic["mass"].astype(np.float64)[:, None]

@@ -120,7 +120,18 @@ def test_dump_errors(tmp_path):
     short.write_bytes(short.read_bytes()[:-100])
     out = nb.bodies_array(10)
     assert lib.nb_read_bodies(str(short).encode(), out.ctypes.data, 10) == L.NB_EFORMAT
-    assert lib.nb_read_bodies(str(short).encode(), out.ctypes.data, 11) == L.NB_EINVAL
+    assert lib.nb_last_error_code() == L.NB_EFORMAT and b"bytes on disk" in lib.nb_last_error()
+    whole = tmp_path / "whole.nbd"
+    nb.write_bodies(whole, b)
+    assert lib.nb_read_bodies(str(whole).encode(), out.ctypes.data, 11) == L.NB_EINVAL
+    # a forged body count (n * 64 wraps a size_t) is refused by the header check: nothing is sized from it
+    raw = bytearray(whole.read_bytes())
+    raw[16:24] = (1 << 58).to_bytes(8, "little")
+    forged = tmp_path / "forged.nbd"
+    forged.write_bytes(bytes(raw))
+    assert lib.nb_read_header(str(forged).encode(), C.byref(n), C.byref(fr), None) == L.NB_EFORMAT
+    with pytest.raises(nb.NBodyError):
+        nb.read_bodies(forged)
 
 
 def test_create_argument_validation():
@@ -128,6 +139,7 @@ def test_create_argument_validation():
     b = nb.plummer_2d(16, 1)
     p = L.default_params()
     assert not lib.nb_create(None, 16, C.byref(p)) and b"no bodies" in lib.nb_last_error()
+    assert lib.nb_last_error_code() == L.NB_EINVAL
     p.struct_size = 4
     assert not lib.nb_create(b.ctypes.data, 16, C.byref(p)) and b"struct_size" in lib.nb_last_error()
     p = L.default_params(); p.precision = 7
@@ -148,6 +160,7 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(nb.NBodyError) as e:
         nb.Simulation(nb.plummer_2d(64, 1))
     assert "no HIP device" in str(e.value)
+    assert e.value.code == L.NB_ENODEVICE and lib.nb_last_error_code() == L.NB_ENODEVICE   # a NULL handle still says why
 
 
 def test_product_does_not_reference_oracle():

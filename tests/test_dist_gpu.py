@@ -28,8 +28,6 @@ def _free_port():
 
 def _worker(rank, world, port, backend, n, steps, precision, out_dir, late_us=None):
     sys.path.insert(0, str(ROOT))
-    if late_us is not None:
-        os.environ["NB_SYM_LATE_US"] = str(late_us)     # read by the library when the handle is created
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -46,12 +44,13 @@ def _worker(rank, world, port, backend, n, steps, precision, out_dir, late_us=No
         dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         ic = nb.plummer_2d(n, 42)
-        sim = DistributedSimulation(ic, eps=0.05, precision=precision, device_index=0)
+        sim = DistributedSimulation(ic, eps=0.05, precision=precision, device_index=0,
+                                    sym_late_us=float(late_us) if late_us is not None else 0.0)
         k0, u0 = sim.energy()
         sim.advance(steps, 1e-3)
         k1, u1 = sim.energy()
         mine = sim.sync().copy()
-        np.save(Path(out_dir) / f"sym_{rank}.npy", np.array([int(sim.symmetric), int("late=0" not in sim.sim.describe())]))
+        np.save(Path(out_dir) / f"sym_{rank}.npy", np.array([int(sim.symmetric), int(sim.sim.sym_info()["items_late"] > 0)]))
         np.save(Path(out_dir) / f"pos_{rank}.npy", mine["pos"])
         np.save(Path(out_dir) / f"vel_{rank}.npy", mine["vel"])
         np.save(Path(out_dir) / f"energy_{rank}.npy", np.array([k0, u0, k1, u1]))

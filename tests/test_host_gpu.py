@@ -90,11 +90,9 @@ def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, prot
     same trajectory as one handle, in both sharding protocols."""
     exe = _host_program("nbody_main")
     dump = tmp_path / "sh.nbd"
-    env = dict(os.environ)
-    if late_us:
-        env["NB_SYM_LATE_US"] = late_us       # hold local items back for the side stream (default from 8 ranks on)
-    r = subprocess.run([str(exe), "-n", str(n), "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)],
-                       capture_output=True, text=True, timeout=120, env=env)
+    extra = ["-late-us", late_us] if late_us else []   # hold local items back for the side stream (default from 8 ranks on)
+    r = subprocess.run([str(exe), "-n", str(n), "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)] + extra,
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert ("late=0" not in r.stdout) == bool(late_us) or protocol == "allgather"
     assert "shards=4" in r.stdout and "frame=6" in r.stdout and f"protocol={protocol}" in r.stdout

@@ -168,34 +168,25 @@ def test_j_slices_and_lane_blocking_agree(nbo, js):
     ic = nb.plummer_2d(8192, 9)
     ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), 0.02)
     ref = np.stack([ax, ay], 1)
-    for P in ("1", "2", "4"):
-        os.environ["NB_FORCE_P"] = P
-        try:
-            with nb.Simulation(ic, eps=0.02, j_slices=js) as sim:
-                acc = sim.accelerations()
-                assert f"j_slices(all)={js}" in sim.describe()
-        finally:
-            del os.environ["NB_FORCE_P"]
+    for P in (1, 2, 4):
+        with nb.Simulation(ic, eps=0.02, j_slices=js, lanes_p=P) as sim:
+            acc = sim.accelerations()
+            assert f"j_slices(all)={js}" in sim.describe() and f"i/lane={2 * P}" in sim.describe()
         assert max_rel(acc, ref) < 1e-4, (js, P)   # per-particle, one long fp32 running sum when js=1
 
 
 def test_uniform_mass_fast_path_matches_general_path(nbo):
     """Equal masses select the kernel variant that hoists the per-pair mass multiply;
-    NB_NO_UNIFORM_MASS=1 forces the general variant.  Both must sit within 1e-5 of fp64."""
+    NB_FLAG_NO_UNIFORM_MASS forces the general variant.  Both must sit within 1e-5 of fp64."""
     ic = nb.plummer_2d(5000, 17)          # ragged: exercises the far-away padding lanes too
     d = nbo.step_f64(nbo.state_from_bodies(ic, np.float64), f32(0.03), f32(1e-3), 8)
     pos64, vel64 = np.stack([d["x"], d["y"]], 1), np.stack([d["vx"], d["vy"]], 1)
     out = {}
-    for tag, env in (("um", None), ("general", "1")):
-        if env:
-            os.environ["NB_NO_UNIFORM_MASS"] = env
-        try:
-            with nb.Simulation(ic, eps=0.03) as sim:
-                assert f"uniform_mass={0 if env else 1}" in sim.describe()
-                sim.advance(8, 1e-3)
-                out[tag] = sim.sync()
-        finally:
-            os.environ.pop("NB_NO_UNIFORM_MASS", None)
+    for tag, um in (("um", True), ("general", False)):
+        with nb.Simulation(ic, eps=0.03, uniform_mass=um) as sim:
+            assert f"uniform_mass={int(um)}" in sim.describe()
+            sim.advance(8, 1e-3)
+            out[tag] = sim.sync()
         assert max_rel(out[tag]["pos"], pos64) < TOL and max_rel(out[tag]["vel"], vel64) < TOL, tag
     assert max_rel(out["um"]["pos"], out["general"]["pos"]) < 2e-6
     # unequal masses never take the fast path
@@ -216,15 +207,10 @@ def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt):
         rng = np.random.default_rng(n)
         ic["mass"] = (rng.uniform(0.5, 1.5, n) / n).astype(np.float32)
     res = {}
-    for tag, env in (("sym", None), ("one_sided", "1")):
-        if env:
-            os.environ["NB_NO_SYMMETRY"] = env
-        try:
-            with nb.Simulation(ic, eps=0.02, rsqrt=rsqrt) as sim:
-                assert f"symmetric={0 if env else 1}" in sim.describe()
-                res[tag] = sim.accelerations().astype(np.float64)
-        finally:
-            os.environ.pop("NB_NO_SYMMETRY", None)
+    for tag, symm in (("sym", True), ("one_sided", False)):
+        with nb.Simulation(ic, eps=0.02, rsqrt=rsqrt, symmetry=symm) as sim:
+            assert f"symmetric={int(symm)}" in sim.describe()
+            res[tag] = sim.accelerations().astype(np.float64)
     scale = np.max(np.abs(res["one_sided"]))
     assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
     if rsqrt == "exact":
@@ -243,18 +229,13 @@ def test_symmetric_fp64_kernel_matches_fp64_direct(nbo, masses):
         ic["mass"] = (np.random.default_rng(3).uniform(0.5, 1.5, n) / n).astype(np.float32)
     st = nbo.state_from_bodies(ic, np.float64)
     res = {}
-    for tag, env in (("sym", None), ("one_sided", "1")):
-        if env:
-            os.environ["NB_NO_SYMMETRY"] = env
-        try:
-            with nb.Simulation(ic, eps=0.02, precision="fp64") as sim:
-                assert f"symmetric={0 if env else 1}" in sim.describe()
-                k, u = sim.energy()
-                sim.advance(4, 1e-3)
-                k1, u1 = sim.energy()
-                res[tag] = (k1 + u1, sim.sync().copy())
-        finally:
-            os.environ.pop("NB_NO_SYMMETRY", None)
+    for tag, symm in (("sym", True), ("one_sided", False)):
+        with nb.Simulation(ic, eps=0.02, precision="fp64", symmetry=symm) as sim:
+            assert f"symmetric={int(symm)}" in sim.describe()
+            k, u = sim.energy()
+            sim.advance(4, 1e-3)
+            k1, u1 = sim.energy()
+            res[tag] = (k1 + u1, sim.sync().copy())
     d = nbo.step_f64(st, f32(0.02), f32(1e-3), 4)
     e_ref = sum(nbo.energy(d, f32(0.02)))
     for tag in res:
@@ -675,13 +656,11 @@ def test_two_million_bodies_symmetric_kernel_properties():
     assert np.max(np.abs(acc[n - own:] - ref)) < 2e-5 * np.max(np.abs(ref))
 
 
-@pytest.mark.parametrize("late_us,aux", [("0", "0"), ("40", "0"), ("40", "1")])
-def test_symmetric_sharded_handles_in_process_match_unsharded(monkeypatch, late_us, aux):
+@pytest.mark.parametrize("late_us,aux", [(-1.0, -1), (40.0, -1), (40.0, 1)])
+def test_symmetric_sharded_handles_in_process_match_unsharded(late_us, aux):
     """Two NB_SHARD_SYMMETRIC handles of N = 131 072 driven from this process (nb_exchange_accelerations /
     nb_exchange_positions): with and without the held-back local items, local items on the main or the side stream."""
     import ctypes
-    monkeypatch.setenv("NB_SYM_LATE_US", late_us)
-    monkeypatch.setenv("NB_SYM_AUX_STREAM", aux)
     lib = nb.load()
     n, parts, steps = 131072, 2, 3
     ic = nb.plummer_2d(n, 8)
@@ -689,10 +668,11 @@ def test_symmetric_sharded_handles_in_process_match_unsharded(monkeypatch, late_
         sim.advance(steps, 1e-3)
         whole = sim.sync()
     blk = n // parts
-    sims = [nb.Simulation(ic, eps=0.02, i_begin=r * blk, i_count=blk, shard_rank=r, shard_world=parts) for r in range(parts)]
+    sims = [nb.Simulation(ic, eps=0.02, i_begin=r * blk, i_count=blk, shard_rank=r, shard_world=parts,
+                          sym_late_us=late_us, sym_aux_stream=aux) for r in range(parts)]
     try:
         assert all(s.shard_protocol == L.NB_SHARD_SYMMETRIC for s in sims)
-        assert all(("late=0" in s.describe()) == (late_us == "0") for s in sims)
+        assert all((s.sym_info()["items_late"] == 0) == (late_us < 0) for s in sims)
         handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
         for _ in range(steps):
             for s in sims:

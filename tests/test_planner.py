@@ -1,24 +1,46 @@
-"""CPU: the symmetric kernel's host-side work planner (nb_debug_sym_plan).  The 8-GPU partition cannot be
-run in this container, so its correctness is checked by construction: over all ranks, every unordered pair
-of (2048-particle tile, 64-particle chunk) is covered exactly once — diagonal items cover a tile's own
-chunks, symmetric items the chunks after it — slab rows are unique, and the ranks' work is balanced."""
+"""CPU: the symmetric kernel's host-side work planner (nb_debug_sym_plan, nbodysim_amd/csrc/nb_plan.cpp).
+The 8-GPU partition cannot be run in this container, so its correctness is checked by construction: over all
+ranks, every unordered pair of (2048-particle tile, 64-particle chunk) is covered exactly once — diagonal
+items cover a tile's own chunks, symmetric items the chunks after it — stationary slab rows are unique, the
+travelling-slab ranges the items write are disjoint and fill the (triangular) slab exactly, and the ranks'
+work is balanced."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
 import nbodysim_amd as nb
+from nbodysim_amd import _lib as L
 
 SB, CH = 2048, 64
 
 
-def plan(n, rank, world, cus=256):
-    lib = nb.load()
-    cnt, nloc, L = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    assert lib.nb_debug_sym_plan(n, cus, rank, world, None, 0, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
-    items = np.zeros((cnt.value, 8), np.uint32)
-    assert lib.nb_debug_sym_plan(n, cus, rank, world, items.ctypes.data, cnt.value, C.byref(cnt), C.byref(nloc), C.byref(L)) == 0
-    return items, int(nloc.value), int(L.value)
+def plan(n, rank, world, cus=256, **tuning):
+    p = None
+    if tuning:
+        p = L.default_params()
+        for k, v in tuning.items():
+            setattr(p, k, v)
+    items, info = L.sym_plan(n, cus, rank, world, p)
+    return items, info
+
+
+def check_slab_ranges(items, info, n, esz=8):
+    """Every non-diagonal item writes elements [r_base + c0*64, r_base + min((c0+cnt)*64, n)) of the travelling slab:
+    the ranges are disjoint and tile the slab exactly (no hole, nothing outside)."""
+    sym = items[items["diag"] == 0]
+    lo = sym["r_base"] + sym["c0"].astype(np.int64) * CH
+    hi = sym["r_base"] + np.minimum((sym["c0"].astype(np.int64) + sym["cnt"]) * CH, n)
+    order = np.argsort(lo)
+    lo, hi = lo[order], hi[order]
+    total = info["slab_r_bytes"] // esz
+    if len(lo) == 0:
+        assert total == 0
+        return
+    assert lo[0] == 0 and hi[-1] == total
+    assert (lo[1:] == hi[:-1]).all()
+    units = int(sym["cnt"].sum())
+    assert total <= units * CH and total > (units - len(set(sym["tile"]))) * CH      # = 64 per unit, ragged last chunk aside
 
 
 @pytest.mark.parametrize("n,world", [(16384, 1), (20000, 1), (70001, 1), (262144, 1), (262144, 2), (262144, 4), (262144, 8),
@@ -28,28 +50,31 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
     cover = np.zeros((tiles, chunks), np.int32)
     work = []
     blk_tiles = tiles if world == 1 else (n // world) // SB
+    cross_totals = set()
     for rank in range(world):
-        items, nloc, L = plan(n, rank, world)
-        assert len(items) > 0 and L >= 1 and 0 < nloc <= len(items)
-        # slab rows: stationary rows unique and dense per rank; one travelling row per (tile, local|cross) part
-        assert sorted(items[:, 3]) == list(range(len(items)))
-        w = 0
-        rrow_of = {}
-        groups = items[:, 6]
-        assert (np.diff(groups.astype(np.int64)) >= 0).all() and (groups[:nloc] == 0).all() and (groups[nloc:] > 0).all()
+        items, info = plan(n, rank, world)
+        nloc, Lc = info["items_local"], info["chunks_per_item"]
+        assert len(items) == info["items"] > 0 and Lc >= 1 and 0 < nloc <= len(items)
+        assert info["items_local"] + info["items_cross"] + info["items_late"] == info["items"]
+        assert info["tiles"] == tiles and info["rows_s"] == len(items)
+        cross_totals.add(info["cross_units_total"])
+        # slab rows: stationary rows unique and dense per rank
+        assert sorted(items["s_row"]) == list(range(len(items)))
+        check_slab_ranges(items, info, n)
+        groups = items["group"].astype(np.int64)
+        assert (np.diff(groups) >= 0).all() and (groups[:nloc] == 0).all() and (groups[nloc:] > 0).all()
         assert (groups == 2).any() == (world >= 8)           # from 8 ranks on a rank holds some local items back (late)
-        for idx, (tile, c0, cnt, s_row, r_row, diag, group, _) in enumerate(items):
-            assert 1 <= cnt <= L and c0 + cnt <= chunks
-            local = group != 1
+        w = 0
+        for it in items:
+            tile, c0, cnt, diag, group = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"]), int(it["group"])
+            assert 1 <= cnt <= Lc and c0 + cnt <= chunks
             if group == 2:
                 assert cnt <= 2
-            if local:   # pairs inside the rank's own block: tile and chunks both in block `rank`
+            if group != 1:   # pairs inside the rank's own block: tile and chunks both in block `rank`
                 assert tile // blk_tiles == rank or world == 1
                 assert c0 + cnt <= min((tile // blk_tiles + 1) * blk_tiles * cpt, chunks)
-            else:       # cross-block pairs: chunks strictly after the tile's block
+            else:            # cross-block pairs: chunks strictly after the tile's block
                 assert not diag and c0 >= (tile // blk_tiles + 1) * blk_tiles * cpt
-            if not diag:
-                assert rrow_of.setdefault((int(tile), int(group)), int(r_row)) == int(r_row)
             if diag:
                 assert tile * cpt <= c0 and c0 + cnt <= min((tile + 1) * cpt, chunks)
                 w += cnt * 48                      # one-sided body cost
@@ -57,8 +82,9 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
                 assert c0 >= (tile + 1) * cpt
                 w += cnt * 56                      # symmetric body cost
             cover[tile, c0:c0 + cnt] += 1
-        assert sorted(set(rrow_of.values())) == list(range(len(set(rrow_of.values()))))
+        assert info["units_local"] + info["units_cross"] + info["units_late"] == int(items["cnt"].sum())
         work.append(w)
+    assert len(cross_totals) == 1                            # rank-independent figure the ranks compare at start-up
     for tile in range(tiles):
         first = tile * cpt
         assert (cover[tile, first:] == 1).all(), tile      # own chunks (diagonal) and every later chunk: once
@@ -68,36 +94,67 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_forced_late_items_keep_the_cover_exact(monkeypatch, world):
-    """NB_SYM_LATE_US forces the held-back (late) group at any world size: still every pair exactly once."""
-    monkeypatch.setenv("NB_SYM_LATE_US", "40")
+def test_forced_late_items_keep_the_cover_exact(world):
+    """nb_params.sym_late_us forces the held-back (late) group at any world size: still every pair exactly once."""
     n = 196608
     tiles, chunks, cpt = n // SB, n // CH, SB // CH
     cover = np.zeros((tiles, chunks), np.int32)
     for rank in range(world):
-        items, nloc, L = plan(n, rank, world)
-        assert (items[:, 6] == 2).any()
-        assert sorted(items[:, 3]) == list(range(len(items)))
-        for tile, c0, cnt, s_row, r_row, diag, group, _ in items:
-            cover[tile, c0:c0 + cnt] += 1
-            if group == 2:
-                assert tile // (tiles // world) == rank and c0 + cnt <= (rank + 1) * (chunks // world)
+        items, info = plan(n, rank, world, sym_late_us=40.0)
+        assert (items["group"] == 2).any() and info["items_late"] == int((items["group"] == 2).sum())
+        assert sorted(items["s_row"]) == list(range(len(items)))
+        check_slab_ranges(items, info, n)
+        for it in items:
+            cover[it["tile"], it["c0"]:it["c0"] + it["cnt"]] += 1
+            if it["group"] == 2:
+                assert it["tile"] // (tiles // world) == rank and it["c0"] + it["cnt"] <= (rank + 1) * (chunks // world)
+        none, info0 = plan(n, rank, world, sym_late_us=-1.0)
+        assert info0["items_late"] == 0
     for tile in range(tiles):
         assert (cover[tile, tile * cpt:] == 1).all() and (cover[tile, :tile * cpt] == 0).all()
 
 
+def test_travelling_slab_is_triangular():
+    """The travelling partials take tiles x n / 2 elements, not tiles x n: 2 GiB at N = 1 048 576 fp32 (4 GiB before),
+    133 MiB at the headline N = 262 144, and the 8 ranks of a sharded run hold an eighth each."""
+    for n, lo, hi in ((262144, 126, 136), (1048576, 2040, 2052)):
+        items, info = plan(n, 0, 1)
+        assert lo * 2**20 <= info["slab_r_bytes"] <= hi * 2**20, info
+        tiles = n // SB
+        assert info["slab_r_bytes"] == 8 * sum(n - (i + 1) * SB for i in range(tiles))
+        assert info["coverage_entries"] == tiles * (tiles - 1) // 2
+    whole = plan(1048576, 0, 1)[1]["slab_r_bytes"]
+    parts = [plan(1048576, r, 8)[1]["slab_r_bytes"] for r in range(8)]
+    assert sum(parts) == whole and max(parts) < 1.05 * whole / 8
+
+
+def test_tuning_fields_replace_the_environment_switches():
+    items, info = plan(262144, 0, 1, sym_chunks_per_item=16)
+    assert info["chunks_per_item"] == 16 and int(items["cnt"].max()) == 16
+    uniform, iu = plan(262144, 0, 1, flags=L.NB_FLAG_NO_GUIDED_TAIL)
+    guided, ig = plan(262144, 0, 1)
+    assert iu["items"] < ig["items"] and int(uniform["cnt"].min()) >= 1
+    assert set(np.unique(uniform[uniform["diag"] == 0]["cnt"])) <= {iu["chunks_per_item"]} | set(range(1, iu["chunks_per_item"]))
+    early, ie = plan(262144, 0, 1, sym_tail=(C.c_float * 3)(0.5, 0.7, 0.9))
+    assert ie["items"] > ig["items"]                         # finer items start earlier in the launch
+
+
 def test_plan_fills_the_chip():
     for n, world, lo, hi in ((262144, 1, 5000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 1400)):
-        items, nloc, L = plan(n, world // 2, world)
-        assert lo <= len(items) <= hi, (n, world, len(items), L)
+        items, info = plan(n, world // 2, world)
+        assert lo <= len(items) <= hi, (n, world, len(items), info["chunks_per_item"])
 
 
 def test_plan_rejects_bad_arguments():
     lib = nb.load()
-    cnt = C.c_uint32()
-    assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, 0, C.byref(cnt), None, None) != 0
-    assert lib.nb_debug_sym_plan(1000, 256, 3, 2, None, 0, C.byref(cnt), None, None) != 0
-    assert lib.nb_debug_sym_plan(100000, 256, 0, 3, None, 0, C.byref(cnt), None, None) != 0   # blocks must be whole tiles
+    info = L.nb_sym_info()
+    info.struct_size = C.sizeof(L.nb_sym_info)
+    assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, None, 0, C.byref(info)) == L.NB_EINVAL
+    assert lib.nb_last_error_code() == L.NB_EINVAL
+    assert lib.nb_debug_sym_plan(1000, 256, 3, 2, None, None, 0, C.byref(info)) != 0
+    assert lib.nb_debug_sym_plan(100000, 256, 0, 3, None, None, 0, C.byref(info)) != 0   # blocks must be whole tiles
+    info.struct_size = 4
+    assert lib.nb_debug_sym_plan(262144, 256, 0, 1, None, None, 0, C.byref(info)) == L.NB_EINVAL
 
 
 def test_local_items_are_a_rank_independent_share():
@@ -105,7 +162,7 @@ def test_local_items_are_a_rank_independent_share():
     all-gather, the held-back (late) ones — about 1400 chunk-units whatever the world size, at most half — the
     reduce-scatter."""
     for world in (2, 4, 8):
-        items, nloc, L = plan(262144, world - 1, world)
-        early, late = items[:nloc, 2].sum(), items[items[:, 6] == 2, 2].sum()
-        assert abs((early + late) / items[:, 2].sum() - 1.0 / world) < 0.03
+        items, info = plan(262144, world - 1, world)
+        early, late = info["units_local"], info["units_late"]
+        assert abs((early + late) / int(items["cnt"].sum()) - 1.0 / world) < 0.03
         assert (1200 <= late <= 1400 and late <= early) if world >= 8 else late == 0
