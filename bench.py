@@ -14,13 +14,24 @@ ranks all-gather their (x,y) blocks every step (RCCL), overlapped with the
 local-tile force.  Prints ONE JSON line on rank 0.
 
 Extra objects in the line:
-  roofline      fp32 vector-ALU roofline of the force kernel: 14 algorithmic flop
-                per pair x pairs per launch / mean launch duration
+  roofline      fp32 vector-ALU roofline of the force kernel.  `achieved` / `frac`
+                are ALGORITHMIC (the contract's definition): 14 flop per ORDERED
+                pair x N^2 pairs per launch / mean launch duration
                 measured with HIP events on the kernel's stream inside the timed
-                region; peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
+                region; peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The symmetric
+                kernel evaluates every UNORDERED pair once, so the flops it really
+                issues are fewer: `executed_tflops` / `executed_frac` count those
+                (17 flop per unordered pair) and are the honest "fraction of the
+                ALU peak" figure; `valu_busy` comes from the PMC profile of the round.
+                `traffic` = HBM bytes of one launch derived from the work plan
+                (slab rows written + positions read); `traffic_pmc` = the counter
+                measurement kept under profiles/ (cross-check).
   cpu_baseline  the oracle (C restatement of the reference's pairwise loop, the
                 reference's own arithmetic) timed on this box's host cores over
                 a bounded i-slice of the same workload.  Rank 0, --gpus 1 only.
+  phases_ms     (N > 1) mean per-step time of each phase of the sharded step on the
+                compute stream (local pairs | all-gather wait | cross pairs |
+                reduce-scatter | kick+drift), so a scaling loss is attributable.
 """
 from __future__ import annotations
 
@@ -43,6 +54,35 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector peak (MI355X_MICROARCH.md, ch
 BYTES_PER_PARTICLE_STEP = 36  # read x,y,m,vx,vy + write x,y,vx,vy (fp32)
 
 
+# flops the kernels really issue: per UNORDERED pair of the symmetric body (both directions) and per
+# ORDERED pair of the one-sided body / of the symmetric kernel's diagonal items; [uniform-mass, general]
+EXECUTED = {
+    ("fp32", 2): {"sym": (17.0, 19.0), "one": (13.0, 14.0)},   # 2 pk_add 2 pk_fma 2 rsq 2 pk_mul (+2 pk_mul) 4|2 pk_fma per 2 pairs
+    ("fp32", 3): {"sym": (24.0, 26.0), "one": (18.0, 19.0)},
+    ("fp64", 2): {"sym": (24.0, 26.0), "one": (15.0, 16.0)},   # v_rsq_f64 + 6-op cube correction (rsqrt3_f64)
+    ("fp64", 3): {"sym": (31.0, 33.0), "one": (19.0, 20.0)},
+}
+
+
+def host_cpu_info():
+    """What "host cores of the GPU box" means for this process: logical CPUs, affinity mask, cgroup quota, model."""
+    info = {"nproc": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["affinity"] = None
+    try:
+        q = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        info["cgroup_cpus"] = None if q[0] == "max" else round(int(q[0]) / int(q[1]), 2)
+    except (OSError, ValueError, IndexError):
+        info["cgroup_cpus"] = None
+    try:
+        info["model"] = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        info["model"] = ""
+    return info
+
+
 def cpu_baseline(ic, n, target_s=12.0):
     """Time the oracle on a bounded i-slice of the same N-body workload."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -59,18 +99,16 @@ def cpu_baseline(ic, n, target_s=12.0):
     t0 = time.perf_counter()
     nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, islice)
     t = time.perf_counter() - t0
-    model = ""
-    try:
-        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
-    except Exception:
-        pass
+    host = host_cpu_info()
     return {
         "value": islice * n / t,
         "unit": "pair interactions/s",
         "cores": threads,
         "kind": "port",
+        "host": host,
         "sample": f"reference pairwise arithmetic (Quake rsqrt, fp32, sequential j) for the first {islice} of {n} "
-                  f"i-particles against all {n} j = {islice * n:.3e} pairs in {t:.2f} s; OpenMP {threads} threads on {model}",
+                  f"i-particles against all {n} j = {islice * n:.3e} pairs in {t:.2f} s; OpenMP {threads} threads "
+                  f"(nproc {host['nproc']}, affinity {host['affinity']}, cgroup quota {host['cgroup_cpus']} CPUs) on {host['model']}",
     }
 
 
@@ -87,16 +125,18 @@ def main() -> None:
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses the multi-rank path on a one-GPU box")
-    ap.add_argument("--protocol", default="auto", choices=["auto", "symmetric", "allgather"],
-                    help="multi-GPU exchange: symmetric pair split (reduce-scatter + all-gather, default where eligible) or the "
-                         "one-sided all-gather protocol (all-gather overlapped with the local-tile force)")
+    ap.add_argument("--protocol", default="tune", choices=["tune", "auto", "symmetric", "allgather"],
+                    help="multi-GPU exchange: tune (default) times a few steps of the symmetric pair split (reduce-scatter + "
+                         "all-gather) and of north_star's all-gather protocol before the timed region and keeps the faster; "
+                         "the others force one")
+    ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
+    ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     args = ap.parse_args()
 
     # RCCL shares device buffers between the ranks of a node through dmabuf IPC on this driver stack
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.protocol == "allgather":
-        os.environ["NB_NO_SYMMETRY"] = "1"      # read by the library at nb_create: one-sided kernels, all-gather protocol
 
     import torch
 
@@ -128,20 +168,22 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-        sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank)
-        inner = sim.sim
-        # bring the communicator up (channels, RCCL kernels) before anything is timed, whatever --warmup is
+        # bring the communicator up (channels, RCCL kernels) before anything is tuned or timed, whatever --warmup is
         scratch = torch.zeros((world * 64, 2), dtype=torch.float32, device="cuda")
         dist.all_gather_into_tensor(scratch, scratch[rank * 64:(rank + 1) * 64])
         if args.backend == "nccl":
             dist.reduce_scatter_tensor(scratch[:64].clone(), scratch, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
+        sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank,
+                                    protocol=args.protocol, tune_dt=DT, uniform_mass=not args.general_mass)
+        inner = sim.sim
         advance, wait = sim.advance, sim.wait
 
         def barrier():
             dist.barrier()
     else:
-        sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims)
+        sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
+                            symmetry=not args.no_symmetry, uniform_mass=not args.general_mass)
         inner = sim
         advance, wait = sim.advance, sim.wait
 
@@ -153,6 +195,8 @@ def main() -> None:
     wait()
     if not args.no_kernel_events:
         inner.profile(True)
+        if world > 1:
+            sim.profile_phases(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -165,34 +209,87 @@ def main() -> None:
     if not args.no_kernel_events:
         force_ms, launches = inner.profile_read()
         inner.profile(False)
+    phases = sim.phase_report() if (world > 1 and not args.no_kernel_events) else None
     k1, u1 = sim.energy()
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        if phases is not None:   # slowest rank per phase, so an exposed collective on any rank shows
+            keys = [k for k, v in phases.items() if isinstance(v, float)]
+            pt = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device="cuda")
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+            phases_max = {k: float(v) for k, v in zip(keys, pt.tolist())}
+        else:
+            phases_max = None
+
+    # secondary figure, outside the timed region and not part of `value`: the same kernel without the equal-mass
+    # specialisation (12 + 2 instead of 10 + 2 instructions per body): what a system with individual masses gets
+    general = None
+    if world == 1 and rank == 0 and not args.no_secondary and not args.general_mass and not args.no_kernel_events:
+        with nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
+                           symmetry=not args.no_symmetry, uniform_mass=False) as g:
+            g.advance(2, DT)
+            g.wait()
+            g.profile(True)
+            g.advance(max(4, args.steps // 2), DT)
+            g.wait()
+            gms, gl = g.profile_read()
+        general = {"avg_launch_ms": gms / gl, "launches": gl}
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)
         value = pairs_per_step * args.steps / elapsed
-        # force launches per step on this rank: 1 (single GPU) or up to 3 (local + remote ranges)
+        peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2
+        info = inner.sym_info()
+        symmetric = bool(info["enabled"])
+        um = "uniform_mass=1" in inner.describe()
+        kernel = ("force_sym" if symmetric else "force_tiled") + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64")
+        # force launches per step on this rank: 1 (single GPU) or up to 3 (local + cross + late / local + remote ranges)
         pairs_this_rank = float(inner.i_count) * float(n) * args.steps
         if launches and force_ms > 0 and world == 1:
             kern_s = force_ms * 1e-3
-            achieved = flop_per_pair * pairs_this_rank / kern_s / 1e12
             avg_launch_ms = force_ms / launches
         else:
             # sharded ranks run their force launches on two streams at once (their event intervals overlap), so the
             # per-rank figure is taken over the wall time of the step, collectives included
-            achieved = flop_per_pair * pairs_this_rank / elapsed / 1e12
+            kern_s = elapsed
             avg_launch_ms = force_ms / launches if launches else None
-        traffic = None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived, written by tools/collect_profile.sh
-        if tfile.exists() and world == 1 and n == N_DEFAULT:
+        achieved = flop_per_pair * pairs_this_rank / kern_s / 1e12
+        # flops the kernel really issues per launch (whole system on one GPU): symmetric items evaluate each unordered
+        # pair once for both particles, the diagonal items and the one-sided kernel every ordered pair
+        ex = EXECUTED[(args.precision, args.dims)]
+        if symmetric and world == 1:
+            diag_units = info["tiles"] * 32.0
+            sym_units = info["units_local"] + info["units_cross"] + info["units_late"] - diag_units
+            exec_flop = (sym_units * ex["sym"][0 if um else 1] + diag_units * ex["one"][0 if um else 1]) * 2048.0 * 64.0
+        elif world == 1:
+            exec_flop = ex["one"][0 if um else 1] * pairs_per_step
+        else:
+            exec_flop = None
+        executed = exec_flop * args.steps / kern_s / 1e12 if exec_flop else None
+        # HBM bytes of one launch from the work plan: every item writes its stationary row and its travelling
+        # partials once (plain stores, no re-reads); the positions (and masses) are read from HBM once, later reads hit L2
+        esz = (8 if args.precision == "fp32" else 16) * (2 if args.dims == 3 else 1)
+        traffic = float(info["slab_s_bytes"] + info["slab_r_bytes"] + n * esz) if (symmetric and world == 1) else None
+        pmc = {}
+        tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived (tools/gpu_round.sh pmc + tools/summarize_profile.py)
+        if tfile.exists() and world == 1:
             try:
-                traffic = json.loads(tfile.read_text()).get("force_kernel_hbm_bytes_per_launch")
+                pmc = json.loads(tfile.read_text())
             except Exception:
-                traffic = None
+                pmc = {}
+        pmc_ok = bool(pmc) and pmc.get("n", N_DEFAULT) == n and (kernel + "<") in pmc.get("kernel", "") and args.dims == 2
+        traffic_pmc = pmc.get("force_kernel_hbm_bytes_per_launch") if pmc_ok else None
+        if world == 1:
+            workload = (f"N={n} {args.precision} direct O(N^2), one MI355X, kernel {kernel}: "
+                        + (f"symmetric pair items ({info['items']} workgroups x {info['chunks_per_item']} chunks of 64, stationary particles in "
+                           f"registers, travelling chunk rotated through the lanes)" if symmetric else "one-sided, j-particles through LDS tiles of 256"))
+        else:
+            workload = (f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, "
+                        + ("symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step"
+                           if sim.symmetric else "all-gather of (x,y) per step overlapped with the local-tile force"))
         line = {
             "metric": f"particle-pair interactions/sec at N={n:,} (direct O(N^2) softened gravity + kick/drift step)",
             "value": value,
@@ -209,38 +306,52 @@ def main() -> None:
             "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": "synthetic (3-D Plummer sphere projected to 2-D, mt19937 seed 42, equal masses, eps=0.01, dt=1e-3)",
             "config": {
-                "workload": f"N={n} {args.precision} direct O(N^2), one MI355X per rank, LDS tile=256" if world == 1 else
-                            f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, "
-                            + ("symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step"
-                               if getattr(sim, "symmetric", False) else "all-gather of (x,y) per step overlapped with the local-tile force"),
+                "workload": workload,
                 "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled", "dims": args.dims,
                 "parallelism": f"i-block x{world}" if world > 1 else "single GPU",
                 "backend": args.backend if world > 1 else None,
+                "protocol": getattr(sim, "protocol", None) if world > 1 else None,
+                "protocol_tuning": getattr(sim, "tuning", None) if world > 1 else None,
+                "uniform_mass_specialisation": um,
                 "launch": inner.describe(),
             },
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved,
-                "peak": PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_FP32_TFLOPS / 2),
+                "frac": achieved / peak,
+                "frac_kind": "algorithmic: 14 flop x N^2 ORDERED pairs / kernel time (the contract's definition); the kernel issues fewer "
+                             "flops than that because it evaluates each unordered pair once - see executed_frac",
+                "executed_tflops": executed,
+                "executed_frac": executed / peak if executed else None,
+                "executed_flop_per_unordered_pair": ex["sym"][0 if um else 1] if symmetric else None,
+                "valu_busy": pmc.get("valu_busy") if pmc_ok else None,
+                "valu_busy_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc run of this command on an MI355X)" if pmc_ok else None,
                 "traffic": traffic,
+                "traffic_source": "work plan: stationary slab rows + travelling partials written once per launch + positions read once",
+                "traffic_pmc": traffic_pmc,
                 "flop_per_pair": flop_per_pair,
-                "kernel": ("force_sym_" if "symmetric=1" in inner.describe() else "force_tiled_") + ("f32" if args.precision == "fp32" else "f64"),
+                "kernel": kernel,
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
+                "general_mass": ({**general, "frac": flop_per_pair * pairs_per_step / (general["avg_launch_ms"] * 1e-3) / 1e12 / peak,
+                                  "note": "same kernel without the equal-mass specialisation (individual masses): untimed secondary run"}
+                                 if general else None),
                 "note": "fp32 vector-ALU bound (no dense contraction for MFMA; the f32 MFMA peak equals the vector peak, 157.3 TF); "
-                        "achieved = 14 ALGORITHMIC flop x N^2 ordered pairs / kernel time; force_sym_f32 evaluates each unordered pair "
-                        "once (Newton's third law), so it executes fewer flops than it delivers; "
-                        "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B",
+                        "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B: HBM is not the bound, the slab traffic is the "
+                        "price of evaluating every pair once with plain stores (no atomics, bit-reproducible)",
                 "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
-                # measured HBM rate of the kernel: PMC bytes per launch (profiles/hbm_traffic.json) over its duration
-                "measured_hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
+                "plan_hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
                 "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic) if traffic else None,
             },
             "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                        "steps": args.warmup + args.steps},
         }
+        if world > 1:
+            line["phases_ms"] = {"rank0": phases, "max_over_ranks": phases_max,
+                                 "note": "per step, on the compute stream (waits included): local pairs | wait for the all-gather | "
+                                         "cross pairs + slab gather | reduce-scatter | kick+drift; the all-gather itself runs on RCCL's stream"}
         if world == 1 and not args.no_cpu_baseline and args.dims == 2:
             line["cpu_baseline"] = cpu_baseline(ic, n)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -4,24 +4,29 @@ Each rank integrates one contiguous block of particles and holds a full-n replic
 of the positions (double buffered, in torch tensors so the collectives write them
 in place).  The library tells which exchange a handle needs (``nb_shard_protocol``):
 
-NB_SHARD_SYMMETRIC (eps > 0, large n — the benchmark case).  Every rank evaluates
-1/world of the UNORDERED pairs with the symmetric kernel — the pairs inside its own
-block plus an equal run of the cross-block pairs — which yields a partial
-acceleration for every particle:
-
-    [compute]  force_sym(pairs inside my block) | wait AG | force_sym(my cross-block run) -> acc_partial[n] | RS | kick, drift
-    [comm   ]  ... all-gather(x,y) of the previous step ...                                  reduce-scatter(sum)   \\-> all-gather
-
-two collectives per step (2 MiB each at N = 262 144, latency-bound), RCCL
-``reduce_scatter_tensor`` / ``all_gather_into_tensor`` over xGMI; the all-gather is
-hidden behind the local pairs (1/world of the rank's work).
-
-NB_SHARD_ALLGATHER (everything else).  i-particles are independent: the only
+NB_SHARD_ALLGATHER — north_star's protocol.  i-particles are independent: the only
 exchange is the all-gather of the drifted (x, y) blocks, overlapped with the
 local-tile force of the next step on the compute stream:
 
     step k:   [compute]  force(local j-block) ......... wait(AG k-1) force(remote) integrate
               [comm   ]  ... all-gather of step k-1's positions ...          \\-> all-gather k
+
+NB_SHARD_SYMMETRIC (eps > 0, large n).  Every rank evaluates 1/world of the UNORDERED
+pairs with the symmetric kernel — the pairs inside its own block plus an equal run of
+the cross-block pairs — which yields a partial acceleration for every particle:
+
+    [compute]  force_sym(pairs inside my block) | wait AG | force_sym(my cross-block run) -> acc_partial[n] | RS | kick, drift
+    [comm   ]  ... all-gather(x,y) of the previous step ...                                  reduce-scatter(sum)   \\-> all-gather
+
+~1.6x fewer VALU cycles per rank for one more latency-bound collective per step
+(``reduce_scatter_tensor``; the all-gather stays hidden behind the local pairs).
+Which of the two is faster on a given node depends on how exposed that second
+collective is, so ``protocol="tune"`` (what ``bench.py`` uses for N > 1) times a few
+steps of each after start-up, the ranks agree on the result by all-reduce, and the
+faster one is kept — the plain all-gather path is the fallback by construction.
+STATUS: the RCCL path with more than one rank has not run on hardware yet (no multi-GPU
+box is reachable from the build container); it is rehearsed over gloo and through RCCL
+with one rank (tests/test_dist_gpu.py, tests/test_dist_gloo.py).
 
 The reference has no distributed code at all; this layer is new.
 PyTorch is plumbing here (device buffers, streams, the process group); the
@@ -29,12 +34,15 @@ force/integrate work is the C ABI's.
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass
-from typing import Optional
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import _lib as L
+
+PROTOCOLS = ("auto", "symmetric", "allgather", "tune")
 
 
 @dataclass(frozen=True)
@@ -91,16 +99,75 @@ def reduce_accelerations(acc_full, acc_owned, plan: ShardPlan, group=None) -> No
         acc_owned.copy_(acc_full[plan.i_begin : plan.i_end])
 
 
+# ---------------------------------------------------------------------------
+# start-up agreement between the ranks (pure torch.distributed: testable over gloo on CPU)
+# ---------------------------------------------------------------------------
+def _comm_device(group=None):
+    import torch
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def ranks_agree(values: Sequence[int], group=None) -> Tuple[bool, list, list]:
+    """True iff every rank passed the same integer vector.  One all-reduce (MAX over [v, -v]); returns
+    (agree, per-entry minimum, per-entry maximum) — identical on every rank, so all of them take the same branch."""
+    import torch
+    import torch.distributed as dist
+
+    v = [int(x) for x in values]
+    t = torch.tensor(v + [-x for x in v], dtype=torch.int64, device=_comm_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    k = len(v)
+    hi = [int(x) for x in t[:k].tolist()]
+    lo = [-int(x) for x in t[k:].tolist()]
+    return lo == hi, lo, hi
+
+
+def agree_on_fastest(local_seconds: Dict[str, float], group=None, prefer: Sequence[str] = ("symmetric", "allgather")):
+    """Every rank passes its own timing of each candidate (``inf`` = candidate unavailable); the job's time of a
+    candidate is the MAX over ranks (the slowest rank sets the step rate).  Returns (winner, {name: job seconds}),
+    identical on every rank; ties and near-ties (within 1 %) go to the earlier name in ``prefer``."""
+    import torch
+    import torch.distributed as dist
+
+    names = sorted(local_seconds)
+    t = torch.tensor([float(local_seconds[k]) for k in names], dtype=torch.float64, device=_comm_device(group))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    job = {k: float(x) for k, x in zip(names, t.tolist())}
+    order = [k for k in prefer if k in job] + [k for k in names if k not in prefer]
+    best = order[0]
+    for k in order[1:]:
+        if job[k] < 0.99 * job[best]:
+            best = k
+    if not np.isfinite(job[best]):
+        raise RuntimeError(f"no sharding protocol is available on every rank: {job}")
+    return best, job
+
+
+_AGREE_FIELDS = ("created", "protocol", "chunks_per_item", "cross_units_total", "local_units", "tiles", "cus", "late")
+
+
 class DistributedSimulation:
-    """Sharded ``Simulation``: one rank of a ``torch.distributed`` job, one GPU."""
+    """Sharded ``Simulation``: one rank of a ``torch.distributed`` job, one GPU.
+
+    protocol   "auto"       the library's choice (symmetric where eligible)
+               "symmetric"  the symmetric pair split; error if the system is not eligible
+               "allgather"  north_star's protocol: one-sided kernels, one all-gather per step
+               "tune"       time ``tune_steps`` steps of each on a scratch copy, keep the faster (ranks agree)
+    Extra keyword arguments go to ``Simulation`` (``sym_late_us``, ``sym_chunks_per_item`` ... the tuning fields of
+    ``nb_params``; they must be the same on every rank and are verified to be).
+    """
 
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
-                 order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0):
+                 order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
+                 protocol: str = "auto", tune_steps: int = 6, tune_dt: float = 1e-3, **sim_kwargs):
         import torch
         import torch.distributed as dist
 
-        from .simulation import Simulation
-
+        if protocol not in PROTOCOLS:
+            raise ValueError(f"protocol must be one of {PROTOCOLS}")
         self.dist = dist
         self.torch = torch
         self.group = group
@@ -111,33 +178,114 @@ class DistributedSimulation:
             device_index = torch.cuda.current_device()
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        dtype = torch.float64 if precision == "fp64" else torch.float32
-        # full-n position replicas owned by torch so the collective can write them
-        self.pos = [torch.empty((self.plan.n, 2), dtype=dtype, device=self.device) for _ in range(2)]
+        self._dtype = torch.float64 if precision == "fp64" else torch.float32
+        self._args = dict(eps=eps, precision=precision, rsqrt=rsqrt, order=order, j_slices=j_slices, **sim_kwargs)
+        self._device_index = device_index
         self.stream = torch.cuda.Stream(self.device)
-        # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
+        self.sim = None
+        self.pos: list = []
         self.acc_full = self.acc_owned = None
-        acc_ptrs = None
+        self._pending = None
+        self.tuning: Optional[dict] = None
+        self._phase_on = False
+        self._phase_events: list = []
+        self._host_enqueue_s = 0.0
+        self._host_steps = 0
+
+        if protocol == "tune" and world > 1:
+            protocol = self._tune(bodies, tune_steps, tune_dt)
+        elif protocol == "tune":
+            protocol = "auto"
+        self._create(bodies, protocol)
+
+    # -- construction ---------------------------------------------------------
+    def _create(self, bodies: np.ndarray, protocol: str) -> None:
+        """Allocate the replicas, create the handle, and verify that every rank got the same pair split.  A rank
+        whose nb_create fails still reaches the collective, so the job fails on every rank instead of hanging."""
+        from .simulation import Simulation
+
+        torch, world, rank = self.torch, self.plan.world, self.plan.rank
+        err: Optional[BaseException] = None
+        self.sim = None
+        try:
+            # full-n position replicas owned by torch so the collective can write them
+            self.pos = [torch.empty((self.plan.n, 2), dtype=self._dtype, device=self.device) for _ in range(2)]
+            # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
+            self.acc_full = self.acc_owned = None
+            acc_ptrs = None
+            if world > 1 and protocol != "allgather":
+                self.acc_full = torch.zeros((self.plan.n, 2), dtype=self._dtype, device=self.device)
+                self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=self._dtype, device=self.device)
+                acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
+            kw = dict(self._args)
+            if protocol == "allgather":
+                kw["symmetry"] = False
+            self.sim = Simulation(
+                bodies, device=self._device_index, i_begin=self.plan.i_begin, i_count=self.plan.i_count,
+                stream=self.stream.cuda_stream, pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
+                shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, **kw,
+            )
+        except (L.NBodyError, RuntimeError, MemoryError) as e:   # keep going to the collective below
+            err = e
+        self.symmetric = err is None and self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
         if world > 1:
-            self.acc_full = torch.zeros((self.plan.n, 2), dtype=dtype, device=self.device)
-            self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=dtype, device=self.device)
-            acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
-        self.sim = Simulation(
-            bodies, eps=eps, precision=precision, rsqrt=rsqrt, order=order, device=device_index, j_slices=j_slices,
-            i_begin=self.plan.i_begin, i_count=self.plan.i_count, stream=self.stream.cuda_stream,
-            pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
-            shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs,
-        )
-        self.symmetric = self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
-        if world > 1:   # the protocol fixes which collectives a step issues: every rank must have chosen the same one
-            t = torch.tensor([self.sim.shard_protocol, -self.sim.shard_protocol], dtype=torch.int64, device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-            if int(t[0]) != -int(t[1]):
-                raise RuntimeError("sharding protocol differs between ranks (different environment or device?)")
+            info = self.sim.sym_info() if err is None else {}
+            vec = [
+                0 if err is not None else 1,
+                0 if err is not None else self.sim.shard_protocol,
+                info.get("chunks_per_item", 0),
+                info.get("cross_units_total", 0),
+                info.get("units_local", 0) + info.get("units_late", 0),
+                info.get("tiles", 0),
+                info.get("cus", 0),
+                1 if info.get("items_late", 0) else 0,
+            ]
+            ok, lo, hi = ranks_agree(vec, self.group)
+            if not ok or lo[0] == 0:
+                if self.sim is not None:
+                    self.sim.close()
+                    self.sim = None
+                what = ", ".join(f"{k}: {a}..{b}" for k, a, b in zip(_AGREE_FIELDS, lo, hi) if a != b) or "nb_create failed on every rank"
+                raise RuntimeError(f"rank {rank}: the ranks did not build the same sharded plan ({what})"
+                                   + (f"; this rank: {err}" if err is not None else "")) from err
+        elif err is not None:
+            raise err
+        if protocol == "symmetric" and world > 1 and not self.symmetric:
+            self.sim.close()
+            raise RuntimeError("protocol='symmetric' requested but the system is not eligible "
+                               "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096)")
+        self.protocol = "symmetric" if self.symmetric else "allgather"
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
 
+    def _tune(self, bodies: np.ndarray, steps: int, dt: float) -> str:
+        """Time `steps` steps of each protocol on a scratch copy of the system (2 untimed steps first), wall clock
+        between barriers, MAX over ranks; the handles are destroyed again, so the simulation proper starts from
+        the caller's bodies at frame 0."""
+        local: Dict[str, float] = {}
+        for cand in ("symmetric", "allgather"):
+            try:
+                self._create(bodies, cand)
+            except RuntimeError as e:
+                if "not eligible" not in str(e):
+                    raise
+                local[cand] = float("inf")
+                continue
+            self.advance(2, dt)
+            self.wait()
+            self.dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            self.advance(steps, dt)
+            self.wait()
+            self.dist.barrier(group=self.group)
+            local[cand] = (time.perf_counter() - t0) / steps
+            self.close()
+        best, job = agree_on_fastest(local, self.group)
+        self.tuning = {"steps": steps, "ms_per_step": {k: v * 1e3 for k, v in job.items()}, "chosen": best}
+        return best
+
+    # -- stepping ---------------------------------------------------------------
     @property
     def frame(self) -> int:
         return self.sim.frame
@@ -146,28 +294,37 @@ class DistributedSimulation:
         """Sum the ranks' partial accelerations; every rank keeps its own block."""
         reduce_accelerations(self.acc_full, self.acc_owned, self.plan, self.group)
 
+    def _mark(self, marks: Optional[list]) -> None:
+        if marks is not None:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record(self.stream)
+            marks.append(ev)
+
     def step(self, dt: Optional[float] = None) -> None:
         """One sharded step; only enqueues (no host sync)."""
-        if self.symmetric:
-            with self.torch.cuda.stream(self.stream):
-                self.sim.step_begin(dt)      # pairs inside my own block: overlaps the all-gather still in flight
-                if self._pending is not None:
-                    self._pending.wait()     # every rank's new positions are in the CURRENT replica
-                    self._pending = None
-                self.sim.step_mid()          # my run of the cross-block pairs -> partial acceleration of all n
-                self._reduce_accelerations() # ordered after the force on this stream by the process group
-                self.sim.step_finish()       # kick, drift of my block -> NEXT becomes CURRENT
-                self._cur ^= 1
-                self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
-            return
+        marks = [] if self._phase_on else None
+        t_host = time.perf_counter()
         with self.torch.cuda.stream(self.stream):
-            self.sim.step_begin(dt)          # local j-block: overlaps the in-flight all-gather
+            self._mark(marks)
+            self.sim.step_begin(dt)          # pairs inside my own block / local j-block: overlaps the all-gather still in flight
+            self._mark(marks)
             if self._pending is not None:
-                self._pending.wait()         # compute stream waits for the remote blocks
+                self._pending.wait()         # compute stream waits: every rank's new positions are in the CURRENT replica
                 self._pending = None
-            self.sim.step_finish()           # remote j-blocks, kick, drift -> NEXT becomes CURRENT
+            self._mark(marks)
+            if self.symmetric:
+                self.sim.step_mid()          # my run of the cross-block pairs -> partial acceleration of all n
+                self._mark(marks)
+                self._reduce_accelerations() # ordered after the force on this stream by the process group
+                self._mark(marks)
+            self.sim.step_finish()           # (all-gather protocol: remote j-blocks,) kick, drift -> NEXT becomes CURRENT
+            self._mark(marks)
             self._cur ^= 1
             self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
+        self._host_enqueue_s += time.perf_counter() - t_host
+        self._host_steps += 1
+        if marks is not None:
+            self._phase_events.append(marks)
 
     def advance(self, nsteps: int, dt: Optional[float] = None) -> None:
         for _ in range(nsteps):
@@ -180,6 +337,33 @@ class DistributedSimulation:
                 self._pending = None
         self.stream.synchronize()
 
+    # -- per-phase timing (HIP events on the compute stream) ----------------------
+    def profile_phases(self, on: bool = True) -> None:
+        self._phase_on = bool(on)
+        self._phase_events = []
+        self._host_enqueue_s, self._host_steps = 0.0, 0
+
+    def phase_report(self) -> dict:
+        """Mean milliseconds per step of each phase AS SEEN BY THE COMPUTE STREAM (waiting included), plus the host's
+        enqueue time per step.  symmetric: local | ag_wait | cross (+ gather of the slabs) | reduce_scatter | finish;
+        all-gather: local | ag_wait | remote_finish.  When the local items run on the side stream
+        (``local_on_side_stream``) their time shows up inside `cross`, which joins them."""
+        self.wait()
+        names = ("local", "ag_wait", "cross", "reduce_scatter", "finish") if self.symmetric else ("local", "ag_wait", "remote_finish")
+        tot = {k: 0.0 for k in names}
+        for marks in self._phase_events:
+            for k, (a, b) in zip(names, zip(marks[:-1], marks[1:])):
+                tot[k] += a.elapsed_time(b)
+        steps = max(1, len(self._phase_events))
+        out = {k: v / steps for k, v in tot.items()}
+        out["stream_total"] = sum(out.values())
+        out["host_enqueue"] = self._host_enqueue_s / max(1, self._host_steps) * 1e3
+        out["steps"] = len(self._phase_events)
+        info, aux = self.sim.sym_info(), int(self._args.get("sym_aux_stream", 0))
+        out["local_on_side_stream"] = bool(self.symmetric and (aux > 0 or (aux == 0 and info["items_local"] <= 4 * info["cus"])))
+        return out
+
+    # -- host views ---------------------------------------------------------------
     def sync(self) -> np.ndarray:
         """Owned block as Body records (each GPU copies back only its block)."""
         self.wait()
@@ -199,10 +383,16 @@ class DistributedSimulation:
         k, u = self.sim.energy()
         if self.plan.world > 1:
             t = self.torch.tensor([k, u], dtype=self.torch.float64, device=self.device)
+            if self.dist.get_backend(self.group) != "nccl":
+                t = t.cpu()
             self.dist.all_reduce(t, group=self.group)
             k, u = float(t[0]), float(t[1])
         return k, u
 
     def close(self) -> None:
-        self.wait()
-        self.sim.close()
+        if self.sim is not None:
+            self.wait()
+            self.sim.close()
+            self.sim = None
+        self.pos = []
+        self.acc_full = self.acc_owned = None

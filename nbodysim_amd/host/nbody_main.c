@@ -11,6 +11,10 @@
  *                            eps = 1, dt = 0.01, velocity clamp + soft boundary (Simulation.hpp:58-65,116-163)
  *              [-shards P]   P sharded handles driven from this one process (device r mod #GPUs),
  *                            exchanged with nb_exchange_positions: multi-GPU without RCCL
+ *              [-no-symmetry] one-sided kernels / all-gather protocol (nb_params.flags)
+ *              [-late-us US] sharded symmetric protocol: local work held back for the side stream (nb_params.sym_late_us)
+ * -load FILE restarts from a dump: eps, dt, precision, rsqrt mode, sum order, integrator and extras come from its
+ * header unless the command line gives them (options are applied in order, so put -load first to override).
  */
 #include "nbody.h"
 
@@ -32,6 +36,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
     size_t n = 65536;
+    uint64_t frame0 = 0;
     int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
@@ -54,7 +59,16 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-sequential")) p.sum_order = NB_SUM_SEQUENTIAL;
         else if (!strcmp(argv[i], "-kdk")) p.integrator = NB_INTEGRATOR_KDK;
         else if (!strcmp(argv[i], "-dump") && i + 1 < argc) dump = argv[++i];
-        else if (!strcmp(argv[i], "-load") && i + 1 < argc) load = argv[++i];
+        else if (!strcmp(argv[i], "-load") && i + 1 < argc) {
+            /* the header's parameters become the defaults of this run; later options override them */
+            load = argv[++i];
+            nb_params fp;
+            CHECK(nb_read_header(load, &n, &frame0, &fp));     /* validates n against the file length */
+            p.eps = fp.eps; p.dt = fp.dt; p.precision = fp.precision; p.rsqrt_mode = fp.rsqrt_mode;
+            p.sum_order = fp.sum_order; p.integrator = fp.integrator; p.extras = fp.extras; p.dims = fp.dims;
+        }
+        else if (!strcmp(argv[i], "-no-symmetry")) p.flags |= NB_FLAG_NO_SYMMETRY;
+        else if (!strcmp(argv[i], "-late-us") && i + 1 < argc) p.sym_late_us = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-shards") && i + 1 < argc) shards = atoi(argv[++i]);
         else DIE("unknown argument %s", argv[i]);
@@ -63,13 +77,12 @@ int main(int argc, char **argv)
     nb_body *bodies;
     if (reference_ics && !n_given) n = 25000;
     if (load) {
-        uint64_t frame;
-        nb_params fp;
-        CHECK(nb_read_header(load, &n, &frame, &fp));
-        bodies = (nb_body *)malloc(n * sizeof *bodies);
+        bodies = (nb_body *)malloc(n * sizeof *bodies);        /* n <= 0x7fffff00 and consistent with the file: checked by nb_read_header */
         if (!bodies) DIE("out of memory");
         CHECK(nb_read_bodies(load, bodies, n));
-        printf("loaded %zu bodies (frame %llu) from %s\n", n, (unsigned long long)frame, load);
+        printf("loaded %zu bodies (frame %llu, eps %g, dt %g, %s%s%s) from %s\n", n, (unsigned long long)frame0, p.eps, p.dt,
+               p.precision == NB_FP64 ? "fp64" : "fp32", p.rsqrt_mode == NB_RSQRT_QUAKE ? ", quake" : "",
+               p.sum_order == NB_SUM_SEQUENTIAL ? ", sequential" : "", load);
     } else {
         bodies = (nb_body *)malloc(n * sizeof *bodies);
         if (!bodies) DIE("out of memory");
@@ -91,7 +104,7 @@ int main(int argc, char **argv)
             if (!h[r]) DIE("nb_create(shard %d): %s", r, nb_last_error());
         }
         const int symmetric = nb_shard_protocol(h[0]) == NB_SHARD_SYMMETRIC;
-        char desc0[640];
+        char desc0[1024];
         CHECK(nb_describe(h[0], desc0, sizeof desc0));
         printf("shard 0: %s\n", desc0);
         const double t0s = now_s();
@@ -118,7 +131,7 @@ int main(int argc, char **argv)
     nb_sim *sim = nb_create(bodies, n, &p);
     if (!sim) DIE("nb_create: %s", nb_last_error());
     const int pinned = nb_host_register(bodies, n * sizeof *bodies) == NB_OK;   /* nb_sync then DMAs into `bodies` */
-    char desc[512];
+    char desc[1024];
     CHECK(nb_describe(sim, desc, sizeof desc));
     printf("%s\n", desc);
 

@@ -190,7 +190,7 @@ class Simulation:
         return info.as_dict()
 
     def describe(self) -> str:
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(1024)
         L.check("nb_describe", self._lib.nb_describe(self._h, buf, len(buf)))
         return buf.value.decode()
 

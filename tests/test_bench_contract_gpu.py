@@ -35,6 +35,14 @@ def test_bench_line_contract():
         assert k in rf
     assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["launches"] == 4 and rf["avg_launch_ms"] > 0          # HIP events around every force launch of the timed region
+    # the whole roofline truth: the symmetric kernel issues fewer flops than the algorithmic count it delivers
+    assert rf["kernel"] == "force_sym_f32" and rf["kernel"] in d["config"]["workload"] and "LDS tile" not in d["config"]["workload"]
+    assert 0 < rf["executed_frac"] < rf["frac"] and abs(rf["executed_frac"] - rf["executed_tflops"] / rf["peak"]) < 1e-9
+    assert abs(rf["executed_frac"] / rf["frac"] - 17.0 / 28.0) < 0.02             # 17 flop per unordered pair vs 2 x 14 algorithmic
+    assert rf["traffic"] > 36 * 32768 and rf["traffic_pmc"] is None              # from the plan; the PMC file is for N = 262 144 only
+    g = rf["general_mass"]
+    assert g["avg_launch_ms"] > rf["avg_launch_ms"] and 0 < g["frac"] < rf["frac"]   # individual masses: 12 + 2 ops per body
+    assert {"nproc", "affinity", "cgroup_cpus", "model"} <= set(d["cpu_baseline"]["host"])
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb
@@ -47,3 +55,6 @@ def test_bench_fp64_and_3d_variants_run():
     assert d["dtype"] == "f64" and d["roofline"]["peak"] == 157.3 / 2 and "cpu_baseline" not in d
     d = run_bench("--n", "16384", "--steps", "2", "--warmup", "1", "--dims", "3", "--no-cpu-baseline")
     assert d["config"]["dims"] == 3 and d["roofline"]["flop_per_pair"] == 20.0
+    d = run_bench("--n", "16384", "--steps", "2", "--warmup", "1", "--no-symmetry", "--no-cpu-baseline")
+    assert d["roofline"]["kernel"] == "force_tiled_f32" and "LDS tiles of 256" in d["config"]["workload"]
+    assert abs(d["roofline"]["executed_frac"] / d["roofline"]["frac"] - 13.0 / 14.0) < 1e-6

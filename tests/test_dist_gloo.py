@@ -177,3 +177,49 @@ def test_two_rank_gloo_symmetric_protocol_matches_unsharded_fp64(tmp_path, nbo):
         v = np.load(tmp_path / f"symvel_rank{r}.npy")
         blk = slice(r * n // world, (r + 1) * n // world)
         assert np.max(np.abs(v - want_vel[blk])) < 1e-11 * np.max(np.abs(want_vel))
+
+
+def _agree_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from nbodysim_amd.dist import agree_on_fastest, ranks_agree
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        # same plan figures on both ranks / one rank built another plan (different chunks per item) / one failed to create
+        res["same"] = ranks_agree([1, 2, 43, 123456789012, 4096, 128, 256, 0])
+        res["diff"] = ranks_agree([1, 2, 43 + rank, 123456789012, 4096, 128, 256, 0])
+        res["failed"] = ranks_agree([rank, 2 * rank, 0, 0, 0, 0, 0, 0])
+        # rank 0 saw the symmetric protocol faster, rank 1 (whose reduce-scatter was exposed) much slower:
+        # the job runs at the slowest rank's pace, so both must pick all-gather
+        res["tune"] = agree_on_fastest({"symmetric": [1.00e-3, 1.60e-3][rank], "allgather": [1.35e-3, 1.30e-3][rank]})
+        # near tie (within 1 %): the preferred (symmetric) protocol wins on both ranks
+        res["tie"] = agree_on_fastest({"symmetric": [1.000e-3, 1.004e-3][rank], "allgather": [1.001e-3, 0.999e-3][rank]})
+        # symmetric unavailable (system not eligible)
+        res["only_ag"] = agree_on_fastest({"symmetric": float("inf"), "allgather": 2e-3})
+        import pickle
+        (Path(out_dir) / f"agree_{rank}.pkl").write_bytes(pickle.dumps(res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_startup_agreement_logic(tmp_path):
+    """The start-up decisions of a sharded run (nbodysim_amd.dist): every rank reaches the same verdict on
+    (a) whether all ranks built the same pair split and (b) which exchange protocol the autotune keeps."""
+    import pickle
+
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (pickle.loads((tmp_path / f"agree_{r}.pkl").read_bytes()) for r in range(world))
+    assert r0 == r1                                                   # identical on every rank: nobody takes another branch
+    assert r0["same"][0] is True and r0["same"][1] == r0["same"][2]
+    assert r0["diff"][0] is False and r0["diff"][1][2] == 43 and r0["diff"][2][2] == 44
+    assert r0["failed"][0] is False and r0["failed"][1][0] == 0      # min(created) == 0: some rank failed nb_create
+    assert r0["tune"][0] == "allgather" and abs(r0["tune"][1]["symmetric"] - 1.6e-3) < 1e-12
+    assert r0["tie"][0] == "symmetric"
+    assert r0["only_ag"][0] == "allgather"

@@ -1,0 +1,213 @@
+"""GPU parity of the BENCHMARKED kernels at the BENCHMARKED sizes (BASELINE.json configs 3, 4, 5), against the
+CPU oracle — not against another GPU kernel and not through a property that holds by construction.
+
+  config 3  N = 262 144 fp32, one GPU (the bench.py line): force_sym_f32 with the plan bench.py runs
+            (same ICs, eps, CU count -> same items), accelerations and a 2-step trajectory of three i-slices
+            (first tile, a middle tile, the last tile) against FP64-DIRECT (nbo.accel_f64 / step_f64), and in
+            `quake` mode against the reference's own arithmetic (nbo.accel_f32 QUAKE = Quadtree.hpp:134-144).
+  config 4  N = 1 048 576 fp32 split 8 ways: eight in-process NB_SHARD_SYMMETRIC handles on this one GPU
+            (nb_exchange_accelerations / nb_exchange_positions), one step, against the unsharded handle and,
+            for one tile, against FP64-DIRECT.
+  config 5  N = 262 144 fp64: one handle and the 8-way split; total energy after two steps against the CPU fp64
+            direct sum (nbo.step_f64 + nbo.energy) to 1e-10, drift reported.
+Tolerances (north_star): positions / velocities 1e-5 relative; accelerations 2e-5 of the force scale max|a|.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import max_rel
+
+import nbodysim_amd as nb
+from nbodysim_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+N, EPS, DT, SEED = 262_144, 0.01, 1e-3, 42      # bench.py's workload
+SB = 2048
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+def slices_of(n):
+    mid = (n // SB // 2) * SB
+    return [(0, SB), (mid, mid + SB), (n - SB, n)]
+
+
+@pytest.fixture(scope="module")
+def headline_ic():
+    return nb.plummer_2d(N, SEED)
+
+
+@pytest.fixture(scope="module")
+def oracle_step1(headline_ic, nbo):
+    """One full fp64 direct-sum step of the whole 262 144-body system on the host cores (6.9e10 pairs)."""
+    st = nbo.state_from_bodies(headline_ic, np.float64)
+    return nbo.step_f64(st, f32(EPS), f32(DT), 1)
+
+
+def test_headline_kernel_accelerations_and_two_steps_vs_fp64_direct(headline_ic, oracle_step1, nbo):
+    ic = headline_ic
+    with nb.Simulation(ic, eps=EPS) as sim:
+        info = sim.sym_info()
+        assert info["enabled"] == 1 and "symmetric=1" in sim.describe() and "uniform_mass=1" in sim.describe()
+        assert info["slab_r_bytes"] == 8 * sum(N - (i + 1) * SB for i in range(N // SB))     # triangular slab
+        acc = sim.accelerations().astype(np.float64)
+        sim.advance(2, DT)
+        two = sim.sync().copy()
+    st0 = nbo.state_from_bodies(ic, np.float64)
+    st1 = oracle_step1
+    scale = None
+    for lo, hi in slices_of(N):
+        ax, ay = nbo.accel_f64(st0, f32(EPS), lo, hi)
+        ref = np.stack([ax[lo:hi], ay[lo:hi]], 1)
+        scale = max(scale or 0.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+        # step 1 of the oracle (all particles) == acc above; step 2 needs the slice's acceleration at x_1 only
+        bx, by = nbo.accel_f64(st1, f32(EPS), lo, hi)
+        v2 = np.stack([st1["vx"][lo:hi] + bx[lo:hi] * f32(DT), st1["vy"][lo:hi] + by[lo:hi] * f32(DT)], 1)
+        x2 = np.stack([st1["x"][lo:hi], st1["y"][lo:hi]], 1) + v2 * f32(DT)
+        assert max_rel(two["pos"][lo:hi], x2) < 1e-5 and max_rel(two["vel"][lo:hi], v2) < 1e-5, (lo, hi)
+    # the oracle's step 1 itself, every particle: x_1 and v_1 after ONE step of the GPU path
+    with nb.Simulation(ic, eps=EPS) as sim:
+        sim.advance(1, DT)
+        one = sim.sync()
+    assert max_rel(one["pos"], np.stack([st1["x"], st1["y"]], 1)) < 1e-5
+    assert max_rel(one["vel"], np.stack([st1["vx"], st1["vy"]], 1)) < 1e-5
+    assert np.max(np.abs(one["acc"].astype(np.float64) - np.stack([st1["ax"], st1["ay"]], 1))) < 2e-5 * np.max(np.abs(st1["ax"]))
+
+
+def test_headline_kernel_general_masses_vs_fp64_direct(headline_ic, nbo):
+    """The same plan without the equal-mass specialisation (12 + 2 instead of 10 + 2 ops per body)."""
+    ic = headline_ic
+    with nb.Simulation(ic, eps=EPS, uniform_mass=False) as sim:
+        assert "symmetric=1" in sim.describe() and "uniform_mass=0" in sim.describe()
+        acc = sim.accelerations().astype(np.float64)
+    st0 = nbo.state_from_bodies(ic, np.float64)
+    for lo, hi in slices_of(N):
+        ax, ay = nbo.accel_f64(st0, f32(EPS), lo, hi)
+        ref = np.stack([ax[lo:hi], ay[lo:hi]], 1)
+        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+
+
+def test_headline_kernel_quake_mode_vs_reference_arithmetic(headline_ic, nbo):
+    """rsqrt = quake on the symmetric kernel against the reference's own pairwise arithmetic (fast_inv_sqrt,
+    fp32, j ascending — Quadtree.hpp:106-111,134-144) at the headline size."""
+    ic = headline_ic
+    with nb.Simulation(ic, eps=EPS, rsqrt="quake") as sim:
+        assert "symmetric=1" in sim.describe()
+        acc = sim.accelerations().astype(np.float64)
+    st = nbo.state_from_bodies(ic)
+    for lo, hi in slices_of(N):
+        ax, ay = nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, lo, hi)
+        ref = np.stack([ax[lo:hi], ay[lo:hi]], 1).astype(np.float64)
+        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+
+
+@pytest.mark.parametrize("n,steps", [(16384, 10), (32768, 4)])
+def test_symmetric_quake_trajectory_within_1e5_of_reference_arithmetic(nbo, n, steps):
+    """The reference-arithmetic 1e-5 bar (positions, velocities) on the SYMMETRIC kernel: quake rsqrt against the
+    restatement of the reference's loop (bit-exact with the compiled reference, tests/test_oracle.py)."""
+    ic = nb.plummer_2d(n, 7)
+    with nb.Simulation(ic, eps=0.05, rsqrt="quake") as sim:
+        assert "symmetric=1" in sim.describe()
+        sim.advance(steps, DT)
+        got = sim.sync()
+    st = nbo.step_f32(nbo.state_from_bodies(ic), 0.05, DT, steps, nbo.RSQRT_QUAKE)
+    assert max_rel(got["pos"], np.stack([st["x"], st["y"]], 1)) < 1e-5
+    assert max_rel(got["vel"], np.stack([st["vx"], st["vy"]], 1)) < 1e-5
+
+
+def test_symmetric_and_one_sided_kernels_agree_at_the_headline_size(headline_ic):
+    """A real cross-check of two different kernels (the round-1 `j_slices` comparison ran the same kernel twice):
+    force_sym_f32 against force_tiled_f32 cut into 8 j-slices."""
+    with nb.Simulation(headline_ic, eps=EPS) as sim:
+        a_sym = sim.accelerations().astype(np.float64)
+    with nb.Simulation(headline_ic, eps=EPS, symmetry=False, j_slices=8) as sim:
+        assert "symmetric=0" in sim.describe() and "j_slices(all)=8" in sim.describe()
+        a_one = sim.accelerations().astype(np.float64)
+    assert np.max(np.abs(a_sym - a_one)) < 2e-5 * np.max(np.abs(a_one))
+    assert not np.array_equal(a_sym, a_one)
+
+
+def _run_split(ic, parts, steps, dt, eps, **kw):
+    """`parts` NB_SHARD_SYMMETRIC handles of one system driven from this process on one GPU."""
+    lib = nb.load()
+    n = ic.shape[0]
+    blk = n // parts
+    sims = [nb.Simulation(ic, eps=eps, i_begin=r * blk, i_count=blk, shard_rank=r, shard_world=parts, **kw) for r in range(parts)]
+    try:
+        assert all(s.shard_protocol == L.NB_SHARD_SYMMETRIC for s in sims)
+        infos = [s.sym_info() for s in sims]
+        # what the ranks of a real run compare at start-up (nbodysim_amd.dist): same L, same cross total
+        assert len({(i["chunks_per_item"], i["cross_units_total"], i["cus"]) for i in infos}) == 1
+        assert sum(i["units_cross"] for i in infos) == infos[0]["cross_units_total"]
+        handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
+        e0 = [s.energy() for s in sims]
+        for _ in range(steps):
+            for s in sims:
+                s.step_begin(dt)
+            for s in sims:
+                s.step_mid()
+            L.check("nb_exchange_accelerations", lib.nb_exchange_accelerations(handles, parts))
+            for s in sims:
+                s.step_finish()
+            L.check("nb_exchange_positions", lib.nb_exchange_positions(handles, parts))
+        e1 = [s.energy() for s in sims]
+        out = nb.bodies_array(n)
+        for s in sims:
+            out[s.i_begin:s.i_begin + s.i_count] = s.sync()
+    finally:
+        for s in sims:
+            s.close()
+    return out, (sum(k for k, _ in e0), sum(u for _, u in e0)), (sum(k for k, _ in e1), sum(u for _, u in e1)), infos
+
+
+def test_config4_one_million_bodies_split_eight_ways(nbo):
+    """BASELINE config 4 (N = 1 048 576 fp32 over 8 GPUs): the 8-way symmetric pair split, all eight ranks' shares run
+    on this one GPU, one step; must equal the unsharded handle, whose last tile is checked against FP64-DIRECT."""
+    n, parts = 1 << 20, 8
+    ic = nb.plummer_2d(n, 4)
+    with nb.Simulation(ic, eps=EPS) as sim:
+        assert sim.sym_info()["slab_r_bytes"] < 2.01 * 2**30                      # 2 GiB (4 GiB before the triangular layout)
+        sim.advance(1, DT)
+        whole = sim.sync().copy()
+    out, _, _, infos = _run_split(ic, parts, 1, DT, EPS)
+    assert all(i["items_late"] > 0 for i in infos)                                 # held-back local items: default from 8 ranks on
+    assert max(i["slab_r_bytes"] for i in infos) < 0.27 * 2**30
+    assert max_rel(out["pos"], whole["pos"]) < 2e-6 and max_rel(out["vel"], whole["vel"]) < 2e-5
+    scale = np.max(np.abs(whole["acc"]))
+    assert np.max(np.abs(out["acc"].astype(np.float64) - whole["acc"])) < 2e-5 * scale
+    lo, hi = n - SB, n
+    ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), f32(EPS), lo, hi)    # 2.1e9 pairs on the host
+    ref = np.stack([ax[lo:hi], ay[lo:hi]], 1)
+    assert np.max(np.abs(out["acc"][lo:hi].astype(np.float64) - ref)) < 2e-5 * np.max(np.abs(ref))
+    assert np.max(np.abs(whole["acc"][lo:hi].astype(np.float64) - ref)) < 2e-5 * np.max(np.abs(ref))
+
+
+def test_config5_fp64_headline_size_single_and_split_energy_vs_cpu(headline_ic, oracle_step1, nbo):
+    """BASELINE config 5 (N = 262 144 fp64, 8 GPUs, energy check vs the CPU reference): force_sym_f64 on one handle and
+    as the 8-way split; total energy after 2 steps equals the CPU fp64 direct sum's to 1e-10; drift printed."""
+    ic, steps = headline_ic, 2
+    st = {k: v.copy() for k, v in oracle_step1.items()}
+    st = nbo.step_f64(st, f32(EPS), f32(DT), 1)                                     # second full step on the host
+    e_cpu0 = sum(nbo.energy(nbo.state_from_bodies(ic, np.float64), f32(EPS)))
+    e_cpu = sum(nbo.energy(st, f32(EPS)))
+    with nb.Simulation(ic, eps=EPS, precision="fp64") as sim:
+        assert "symmetric=1" in sim.describe() and "fp64" in sim.describe()
+        k0, u0 = sim.energy()
+        sim.advance(steps, DT)
+        k1, u1 = sim.energy()
+        single = sim.sync().copy()
+    out, (sk0, su0), (sk1, su1), infos = _run_split(ic, 8, steps, DT, EPS, precision="fp64")
+    print(f"config 5: E0 = {k0 + u0:.12e} (CPU {e_cpu0:.12e}); after {steps} steps single {k1 + u1:.12e}, 8-way {sk1 + su1:.12e}, "
+          f"CPU {e_cpu:.12e}; relative drift {(k1 + u1 - k0 - u0) / (k0 + u0):.3e}")
+    assert abs(k0 + u0 - e_cpu0) < 1e-10 * abs(e_cpu0) and abs(sk0 + su0 - e_cpu0) < 1e-10 * abs(e_cpu0)
+    assert abs(k1 + u1 - e_cpu) < 1e-10 * abs(e_cpu)
+    assert abs(sk1 + su1 - e_cpu) < 1e-10 * abs(e_cpu)
+    assert abs((k1 + u1 - k0 - u0) / (k0 + u0)) < 1e-5
+    pos = np.stack([st["x"], st["y"]], 1)
+    assert max_rel(single["pos"], pos) < 2e-7 and max_rel(out["pos"], pos) < 2e-7   # float output records

@@ -22,6 +22,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+n_run = int(sys.argv[2]) if len(sys.argv) > 2 else 262144          # N of the profiled bench.py command
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 
@@ -67,7 +68,8 @@ print("pmc summary ->", out / f"{tag}_pmc_summary.json")
 force_keys = [k for k in derived if "force_sym_f32" in k] or [k for k in derived if "force_tiled_f32" in k]
 for k, x in derived.items():
     if k in force_keys[:1] and "hbm_read_bytes_corrected" in x and "hbm_write_bytes" in x:
-        t = {"round": tag, "kernel": k, "force_kernel_hbm_bytes_per_launch": x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"],
+        t = {"round": tag, "kernel": k, "n": n_run, "valu_busy": x.get("valu_busy_frac"), "l2_hit_rate": x.get("l2_hit_rate"),
+             "force_kernel_hbm_bytes_per_launch": x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"],
              "read_bytes_raw_FETCH_SIZE": x["hbm_read_bytes_raw"], "read_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
              "write_bytes_WRITE_SIZE": x["hbm_write_bytes"]}
         (out / "hbm_traffic.json").write_text(json.dumps(t, indent=1) + "\n")
