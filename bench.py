@@ -132,6 +132,7 @@ def main() -> None:
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
+    ap.add_argument("--chunks-per-item", type=int, default=0, help="symmetric kernel: force nb_params.sym_chunks_per_item (tuning sweeps)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     args = ap.parse_args()
 
@@ -183,7 +184,7 @@ def main() -> None:
             dist.barrier()
     else:
         sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
-                            symmetry=not args.no_symmetry, uniform_mass=not args.general_mass)
+                            symmetry=not args.no_symmetry, uniform_mass=not args.general_mass, sym_chunks_per_item=args.chunks_per_item)
         inner = sim
         advance, wait = sim.advance, sim.wait
 

@@ -59,7 +59,7 @@ struct nb_sim {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool fp64 = false;
-    bool dims3 = false;        // 3-D variant: float4 {x,y,z,m} positions, float4 velocities / accelerations / slabs
+    bool dims3 = false;        // 3-D variant: real4 {x,y,z,m} positions, real4 velocities / accelerations / slabs
     size_t rsz = 4;            // sizeof(real)
     size_t esz = 8;            // bytes of one position / velocity / acceleration / slab element
 
@@ -369,7 +369,7 @@ static void free_all(nb_sim *s)
 static int do_upload(nb_sim *s, const nb_body *in)
 {
     // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
-    // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_NO_UNIFORM_MASS=1 disables it.
+    // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_FLAG_NO_UNIFORM_MASS disables it.
     s->uniform_mass = s->n > 0 && !(s->p.flags & NB_FLAG_NO_UNIFORM_MASS) && s->p.sum_order == NB_SUM_TILED;
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
@@ -378,9 +378,12 @@ static int do_upload(nb_sim *s, const nb_body *in)
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
     for (int b = 0; b < 2; ++b) {
-        if (s->dims3)
-            unpack_bodies3<<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (float4 *)s->pos[b], (float4 *)s->vel, (float4 *)s->acc, s->radius,
-                                                       (uint32_t)s->i_begin, (uint32_t)s->i_count);
+        if (s->dims3 && s->fp64)
+            unpack_bodies3<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (double4 *)s->pos[b], (double4 *)s->vel, (double4 *)s->acc, s->radius,
+                                                               (uint32_t)s->i_begin, (uint32_t)s->i_count);
+        else if (s->dims3)
+            unpack_bodies3<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (float4 *)s->pos[b], (float4 *)s->vel, (float4 *)s->acc, s->radius,
+                                                              (uint32_t)s->i_begin, (uint32_t)s->i_count);
         else if (s->fp64)
             unpack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, n, (double2 *)s->pos[b], (double *)s->mass,
                                                              (double2 *)s->vel, (double2 *)s->acc, s->radius,
@@ -420,9 +423,9 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     }
     if (p.dims == 0) p.dims = 2;
     if (p.dims != 2 && p.dims != 3) { nb_set_error("nb_create: dims must be 2 or 3"); return nullptr; }
-    if (p.dims == 3 && (p.precision != NB_FP32 || p.sum_order != NB_SUM_TILED || p.extras != 0 ||
-                        (p.i_count != 0 && p.i_count != n) || p.shard_world > 1)) {
-        nb_set_error("nb_create: dims = 3 supports fp32, tiled sum, no extras, unsharded handles");
+    if (p.dims == 3 && (p.sum_order != NB_SUM_TILED || p.extras != 0)) {
+        nb_set_error("nb_create: dims = 3 supports the tiled sum without extras (the reference defines its sequential order and "
+                     "iterate()'s clamp / boundary in the plane only)");
         return nullptr;
     }
     if (p.i_count == 0) { p.i_begin = 0; p.i_count = n; }
@@ -443,7 +446,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->fp64 = p.precision == NB_FP64;
     s->rsz = s->fp64 ? 8 : 4;
     s->dims3 = p.dims == 3;
-    s->esz = s->dims3 ? sizeof(float4) : 2 * s->rsz;
+    s->esz = (s->dims3 ? 4 : 2) * s->rsz;      // one position / velocity / acceleration / slab element: real2 or real4
 
     auto fail = [&](const char *what, hipError_t e) -> nb_sim * {
         free_all(s);
@@ -575,7 +578,13 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
     const uint32_t n = (uint32_t)s->n;
     const SymItem *items = s->sym_items_dev + first;
     const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
-    if (s->dims3) {
+    if (s->dims3 && s->fp64) {
+        const double eps2 = (double)s->p.eps * (double)s->p.eps;
+        const double4 *pos = (const double4 *)s->pos[s->cur];
+        double4 *ss = (double4 *)s->sym_slab_s, *sr = (double4 *)s->sym_slab_r;
+        if (s->uniform_mass) force_sym3_f64<true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, (double)s->um_mass);
+        else                 force_sym3_f64<false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0);
+    } else if (s->dims3) {
         const float eps2 = s->p.eps * s->p.eps;
         const float4 *pos = (const float4 *)s->pos[s->cur];
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
@@ -620,15 +629,24 @@ static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
     const uint32_t *lo = s->sym_rowbase_dev, *hi = s->sym_rowbase_dev + tiles;      // [first row, first late row)
     const uint32_t *cb = s->sym_cov_begin_dev;                                      // coverage lists of the main gather
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
-    if (s->dims3) {
+    if (s->dims3 && s->fp64) {
+        const double4 *ss = (const double4 *)s->sym_slab_s, *sr = (const double4 *)s->sym_slab_r;
+        if (fuse_step)
+            sym_gather3<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double4 *)dst, nullptr,
+                                                                   (const double4 *)s->pos[s->cur], (double4 *)s->pos[nxt], (double4 *)s->vel, (double4 *)s->acc,
+                                                                   dt, dt, kd);
+        else
+            sym_gather3<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double4 *)dst, nullptr,
+                                                                    nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0);
+    } else if (s->dims3) {
         const float4 *ss = (const float4 *)s->sym_slab_s, *sr = (const float4 *)s->sym_slab_r;
         if (fuse_step)
-            sym_gather3<true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, (float4 *)dst,
-                                                           (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
-                                                           (float)dt, (float)dt, kd);
+            sym_gather3<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float4 *)dst, nullptr,
+                                                                  (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                                  (float)dt, (float)dt, kd);
         else
-            sym_gather3<false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, (float4 *)dst,
-                                                            nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0);
+            sym_gather3<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float4 *)dst, nullptr,
+                                                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0);
     } else if (s->fp64) {
         const double2 *ss = (const double2 *)s->sym_slab_s, *sr = (const double2 *)s->sym_slab_r;
         if (fuse_step)
@@ -662,7 +680,17 @@ static int launch_sym_gather_late(nb_sim *s, double dt)
     const uint32_t *cb = s->sym_cov_begin_dev + (tiles + 1);                        // coverage lists of the late segments
     const SymCov *cov = s->sym_cov_dev + s->sym_cov_late_off;
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
-    if (s->fp64)
+    if (s->dims3 && s->fp64)
+        sym_gather3<double, true><<<gg, BLOCK, 0, s->stream>>>((const double4 *)s->sym_slab_s, (const double4 *)s->sym_slab_r, lo, hi, cb, cov,
+                                                               n, ib, ic, nullptr, (const double4 *)s->acc_owned,
+                                                               (const double4 *)s->pos[s->cur], (double4 *)s->pos[nxt], (double4 *)s->vel, (double4 *)s->acc,
+                                                               dt, dt, kd);
+    else if (s->dims3)
+        sym_gather3<float, true><<<gg, BLOCK, 0, s->stream>>>((const float4 *)s->sym_slab_s, (const float4 *)s->sym_slab_r, lo, hi, cb, cov,
+                                                              n, ib, ic, nullptr, (const float4 *)s->acc_owned,
+                                                              (const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                              (float)dt, (float)dt, kd);
+    else if (s->fp64)
         sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, lo, hi, cb, cov,
                                                               n, ib, ic, nullptr, (const double2 *)s->acc_owned,
                                                               (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
@@ -692,6 +720,21 @@ static int launch_force(nb_sim *s, const ForceJob &j)
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
     const bool guard = s->p.eps == 0.0f;
     const uint32_t ic = (uint32_t)s->i_count;
+    if (s->dims3 && s->fp64) {
+        const double eps2 = (double)s->p.eps * (double)s->p.eps;
+        const uint32_t grid = grid_blocks(j.i_tiles, j.js);
+        double4 *out = (double4 *)s->partial + (size_t)j.slab0 * s->i_count;
+        const double4 *pos = (const double4 *)s->pos[s->cur];
+#define NB_LAUNCH3D(PP, GD)                                                                                            \
+        force_tiled3_f64<PP, GD, 4><<<grid, BLOCK, 0, s->stream>>>(pos, out, (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, j.js, j.i_tiles, \
+                                                                   eps2, j.gap_begin, j.gap_len)
+        if (j.P == 2) { if (guard) NB_LAUNCH3D(2, true); else NB_LAUNCH3D(2, false); }
+        else          { if (guard) NB_LAUNCH3D(1, true); else NB_LAUNCH3D(1, false); }
+#undef NB_LAUNCH3D
+        HIPCHK(hipGetLastError());
+        if (s->prof && prof_end(s, pr)) return NB_EHIP;
+        return NB_OK;
+    }
     if (s->dims3) {
         const float eps2 = s->p.eps * s->p.eps;
         const uint32_t grid = grid_blocks(j.i_tiles, j.js);
@@ -700,7 +743,7 @@ static int launch_force(nb_sim *s, const ForceJob &j)
         const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE, um = s->uniform_mass && !guard;
 #define NB_LAUNCH3(PP, RQ, GD, UMM)                                                                                   \
         force_tiled3_f32<PP, RQ, GD, 8, UMM><<<grid, BLOCK, 0, s->stream>>>(pos, out, (uint32_t)s->i_begin, ic, j.j_begin, j.j_end, \
-                                                                            j.js, j.i_tiles, eps2, um ? s->um_mass : 1.0f)
+                                                                            j.js, j.i_tiles, eps2, um ? s->um_mass : 1.0f, j.gap_begin, j.gap_len)
 #define NB_DISPATCH3(PP)                                                                                              \
         do {                                                                                                          \
             if (guard)      { if (quake) NB_LAUNCH3(PP, RSQ_QUAKE, true, false); else NB_LAUNCH3(PP, RSQ_EXACT, true, false); }   \
@@ -752,9 +795,12 @@ static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double d
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     const bool strict = s->p.sum_order == NB_SUM_SEQUENTIAL;
     const int nxt = s->cur ^ 1;
-    if (s->dims3)
-        integrate3<<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
-                                               (const float4 *)s->partial, nslabs, (uint32_t)s->i_begin, ic, (float)dt_kick, (float)dt_drift, flags);
+    if (s->dims3 && s->fp64)
+        integrate3<double><<<g, BLOCK, 0, s->stream>>>((const double4 *)s->pos[s->cur], (double4 *)s->pos[nxt], (double4 *)s->vel, (double4 *)s->acc,
+                                                       (const double4 *)s->partial, nslabs, (uint32_t)s->i_begin, ic, dt_kick, dt_drift, flags);
+    else if (s->dims3)
+        integrate3<float><<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                      (const float4 *)s->partial, nslabs, (uint32_t)s->i_begin, ic, (float)dt_kick, (float)dt_drift, flags);
     else if (s->fp64)
         integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
                                                              (double2 *)s->acc, (const double2 *)s->partial, nslabs,
@@ -841,7 +887,14 @@ extern "C" int nb_step_finish(nb_sim *s)
         if (s->sym_items_late) {
             HIPCHK(hipStreamWaitEvent(s->stream, s->ev_late, 0));
             if ((rc = launch_sym_gather_late(s, (double)dt))) return rc;
-        } else if (s->fp64)
+        } else if (s->dims3 && s->fp64)
+            integrate3<double><<<g, BLOCK, 0, s->stream>>>((const double4 *)s->pos[s->cur], (double4 *)s->pos[nxt], (double4 *)s->vel, (double4 *)s->acc,
+                                                           (const double4 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic, (double)dt, (double)dt,
+                                                           INTEG_KICK | INTEG_DRIFT);
+        else if (s->dims3)
+            integrate3<float><<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                          (const float4 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic, dt, dt, INTEG_KICK | INTEG_DRIFT);
+        else if (s->fp64)
             integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
                                                                  (double2 *)s->acc, (const double2 *)s->acc_owned, 1u, (uint32_t)s->i_begin, ic,
                                                                  (double)dt, (double)dt, s->p.extras, INTEG_KICK | INTEG_DRIFT);
@@ -974,9 +1027,12 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
     const bool direct = is_pinned_host(out);
     if (!direct && ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
-    if (s->dims3)
-        pack_bodies3<<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float4 *)s->pos[s->cur], (const float4 *)s->vel, (const float4 *)s->acc,
-                                                 s->radius, (uint32_t)s->i_begin, ic);
+    if (s->dims3 && s->fp64)
+        pack_bodies3<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double4 *)s->pos[s->cur], (const double4 *)s->vel, (const double4 *)s->acc,
+                                                         s->radius, (uint32_t)s->i_begin, ic);
+    else if (s->dims3)
+        pack_bodies3<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float4 *)s->pos[s->cur], (const float4 *)s->vel, (const float4 *)s->acc,
+                                                        s->radius, (uint32_t)s->i_begin, ic);
     else if (s->fp64)
         pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double2 *)s->pos[s->cur], (const double *)s->mass,
                                                         (const double2 *)s->vel, (const double2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
@@ -1016,9 +1072,12 @@ extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
     if (bind(s)) return NB_EHIP;
     const uint32_t g = (uint32_t)s->ered_blocks;
     const double eps2 = (double)s->p.eps * (double)s->p.eps;
-    if (s->dims3)
-        energy_partials3<<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (const float4 *)s->vel, (uint32_t)s->n,
-                                                     (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2, s->ered_dev, s->ered_dev + g);
+    if (s->dims3 && s->fp64)
+        energy_partials3<double><<<g, BLOCK, 0, s->stream>>>((const double4 *)s->pos[s->cur], (const double4 *)s->vel, (uint32_t)s->n,
+                                                             (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2, s->ered_dev, s->ered_dev + g);
+    else if (s->dims3)
+        energy_partials3<float><<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (const float4 *)s->vel, (uint32_t)s->n,
+                                                            (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2, s->ered_dev, s->ered_dev + g);
     else if (s->fp64)
         energy_partials<double><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (const double *)s->mass, (const double2 *)s->vel,
                                                             (uint32_t)s->n, (uint32_t)s->i_begin, (uint32_t)s->i_count, eps2,
@@ -1091,8 +1150,10 @@ extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
         for (int r = 0; r < count; ++r)                          // peers' memory must be mapped on this device
             if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
-        if (s->fp64) sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (double2 *)s->acc_owned);
-        else         sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float2 *)s->acc_owned);
+        if (s->dims3 && s->fp64) sum_partials<double4><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (double4 *)s->acc_owned);
+        else if (s->dims3)       sum_partials<float4><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float4 *)s->acc_owned);
+        else if (s->fp64)        sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (double2 *)s->acc_owned);
+        else                     sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float2 *)s->acc_owned);
         HIPCHK(hipGetLastError());
     }
     for (int a = 0; a < count; ++a) {

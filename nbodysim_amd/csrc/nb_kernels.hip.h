@@ -894,6 +894,11 @@ void integrate(const typename vec2_of<real>::type *__restrict__ pos_cur,
 // ---------------------------------------------------------------------------
 struct PartialPtrs { const void *p[64]; };
 
+__device__ __forceinline__ void add_to(float2 &a, const float2 &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void add_to(double2 &a, const double2 &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void add_to(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; }
+__device__ __forceinline__ void add_to(double4 &a, const double4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; }
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK)
 void sum_partials(PartialPtrs src, int count, uint32_t first, uint32_t cnt, T *__restrict__ dst)
@@ -901,10 +906,7 @@ void sum_partials(PartialPtrs src, int count, uint32_t first, uint32_t cnt, T *_
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
     T a = static_cast<const T *>(src.p[0])[first + k];
-    for (int r = 1; r < count; ++r) {
-        const T b = static_cast<const T *>(src.p[r])[first + k];
-        a.x += b.x; a.y += b.y;
-    }
+    for (int r = 1; r < count; ++r) add_to(a, static_cast<const T *>(src.p[r])[first + k]);
     dst[k] = a;
 }
 

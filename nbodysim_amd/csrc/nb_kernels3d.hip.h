@@ -7,58 +7,71 @@
 // component (20 algorithmic flop per pair instead of 14).  There is no reference arithmetic to be
 // bit-exact with here: parity is against the fp64 restatement only ("parity unpinned").
 //
-// Device layout: positions as float4 {x, y, z, m} (one 16-byte load per particle; the mass rides
-// along), velocities / accelerations / slab rows as float4 {·, ·, ·, 0}.
-// Kernels mirror the 2-D ones of nb_kernels.hip.h:
-//   force_sym3_f32    symmetric (Newton's third law) fast path, lane-rotated travelling particles
-//   force_tiled3_f32  one-sided LDS-tiled kernel (small n, eps = 0, cross-check)
-//   sym_gather3 / integrate3 / pack3 / unpack3 / energy3
+// Device layout: positions as real4 {x, y, z, m} (float4: one 16-byte load per particle; double4: two; the
+// mass rides along), velocities / accelerations / slab rows as real4 {·, ·, ·, 0}.
+// Kernels mirror the 2-D ones of nb_kernels.hip.h, in fp32 and fp64:
+//   force_sym3_f32 / _f64    symmetric (Newton's third law) fast path, lane-rotated travelling particles
+//   force_tiled3_f32 / _f64  one-sided LDS-tiled kernel (small n, eps = 0, all-gather sharding, cross-check);
+//                            the j range skips [gap_begin, gap_begin + gap_len) like the 2-D kernels
+//   sym_gather3 / integrate3 / pack3 / unpack3 / energy3 / (sum_partials of nb_kernels.hip.h)
 #pragma once
 #include "nb_kernels.hip.h"
 
 namespace nbk {
 
+template <typename real> struct vec4_of;
+template <> struct vec4_of<float> { typedef float4 type; };
+template <> struct vec4_of<double> { typedef double4 type; };
+
+template <typename real> __device__ __forceinline__ typename vec4_of<real>::type make_real4(real x, real y, real z, real w);
+template <> __device__ __forceinline__ float4 make_real4<float>(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+template <> __device__ __forceinline__ double4 make_real4<double>(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
+
 // ---------------------------------------------------------------------------
 // kick/drift for one particle, 3 components (the 2-D extras — velocity clamp, soft
 // boundary — are defined by the reference in the plane only and are not applied).
 // ---------------------------------------------------------------------------
+template <typename real>
 __device__ __forceinline__
-void kick_drift_one3(float4 a, uint32_t li, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
-                     float4 *__restrict__ vel, float4 *__restrict__ acc, uint32_t i_begin,
-                     float dt_kick, float dt_drift, int flags)
+void kick_drift_one3(typename vec4_of<real>::type a, uint32_t li, const typename vec4_of<real>::type *__restrict__ pos_cur,
+                     typename vec4_of<real>::type *__restrict__ pos_next, typename vec4_of<real>::type *__restrict__ vel,
+                     typename vec4_of<real>::type *__restrict__ acc, uint32_t i_begin, real dt_kick, real dt_drift, int flags)
 {
-    a.w = 0.f;
+    typedef typename vec4_of<real>::type real4;
+    a.w = 0;
     acc[li] = a;
     if (!(flags & INTEG_KICK)) return;
-    float4 v = vel[li];
-    const float4 x = pos_cur[i_begin + li];
-    v.x = __builtin_fmaf(a.x, dt_kick, v.x);
-    v.y = __builtin_fmaf(a.y, dt_kick, v.y);
-    v.z = __builtin_fmaf(a.z, dt_kick, v.z);
+    real4 v = vel[li];
+    const real4 x = pos_cur[i_begin + li];
+    v.x = __builtin_fma(a.x, dt_kick, v.x);
+    v.y = __builtin_fma(a.y, dt_kick, v.y);
+    v.z = __builtin_fma(a.z, dt_kick, v.z);
     vel[li] = v;
     if (flags & INTEG_DRIFT) {
-        float4 xn;
-        xn.x = __builtin_fmaf(v.x, dt_drift, x.x);
-        xn.y = __builtin_fmaf(v.y, dt_drift, x.y);
-        xn.z = __builtin_fmaf(v.z, dt_drift, x.z);
+        real4 xn;
+        xn.x = __builtin_fma(v.x, dt_drift, x.x);
+        xn.y = __builtin_fma(v.y, dt_drift, x.y);
+        xn.z = __builtin_fma(v.z, dt_drift, x.z);
         xn.w = x.w;                                  // the mass travels with the position
         pos_next[i_begin + li] = xn;
     }
 }
 
+template <typename real>
 __global__ __launch_bounds__(BLOCK)
-void integrate3(const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next, float4 *__restrict__ vel,
-                float4 *__restrict__ acc, const float4 *__restrict__ partial, uint32_t nslabs,
-                uint32_t i_begin, uint32_t i_count, float dt_kick, float dt_drift, int flags)
+void integrate3(const typename vec4_of<real>::type *__restrict__ pos_cur, typename vec4_of<real>::type *__restrict__ pos_next,
+                typename vec4_of<real>::type *__restrict__ vel, typename vec4_of<real>::type *__restrict__ acc,
+                const typename vec4_of<real>::type *__restrict__ partial, uint32_t nslabs,
+                uint32_t i_begin, uint32_t i_count, real dt_kick, real dt_drift, int flags)
 {
     const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
     if (li >= i_count) return;
-    float4 a = partial[li];
+    auto a = partial[li];
     for (uint32_t s = 1; s < nslabs; ++s) {
-        const float4 b = partial[(size_t)s * i_count + li];
+        const auto b = partial[(size_t)s * i_count + li];
         a.x += b.x; a.y += b.y; a.z += b.z;
     }
-    kick_drift_one3(a, li, pos_cur, pos_next, vel, acc, i_begin, dt_kick, dt_drift, flags);
+    kick_drift_one3<real>(a, li, pos_cur, pos_next, vel, acc, i_begin, dt_kick, dt_drift, flags);
 }
 
 // ---------------------------------------------------------------------------
@@ -69,7 +82,7 @@ template <int P, int RSQ, bool GUARD, int UNROLL, bool UM>
 __global__ __launch_bounds__(BLOCK)
 void force_tiled3_f32(const float4 *__restrict__ pos, float4 *__restrict__ partial,
                       uint32_t i_begin, uint32_t i_count, uint32_t j_begin, uint32_t j_end,
-                      uint32_t js, uint32_t i_tiles, float eps2, float um_mass)
+                      uint32_t js, uint32_t i_tiles, float eps2, float um_mass, uint32_t gap_begin, uint32_t gap_len)
 {
     constexpr int WS = 4;
     constexpr uint32_t LANES_I = BLOCK / WS, IT = LANES_I * 2 * P, JW = TJ / WS;
@@ -101,14 +114,14 @@ void force_tiled3_f32(const float4 *__restrict__ pos, float4 *__restrict__ parti
     {
         const uint32_t j = s0 + t;
         v4f q = pad;
-        if (j < s1) { const float4 r = pos[j]; q = (v4f){r.x, r.y, r.z, r.w}; }
+        if (j < s1) { const float4 r = pos[j + (j >= gap_begin ? gap_len : 0u)]; q = (v4f){r.x, r.y, r.z, r.w}; }
         tile[0][t] = q;
     }
     __syncthreads();
     for (uint32_t it = 0; it < ntiles; ++it) {
         v4f qn = pad;
         const uint32_t jn1 = s0 + (it + 1) * TJ + t;
-        if (jn1 < s1) { const float4 r = pos[jn1]; qn = (v4f){r.x, r.y, r.z, r.w}; }
+        if (jn1 < s1) { const float4 r = pos[jn1 + (jn1 >= gap_begin ? gap_len : 0u)]; qn = (v4f){r.x, r.y, r.z, r.w}; }
         const v4f *__restrict__ cur = tile[it & 1] + w * JW;
 #pragma unroll UNROLL
         for (int jj = 0; jj < (int)JW; ++jj) {
@@ -279,82 +292,258 @@ void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ 
     }
 }
 
-// sum of the stationary rows of particle k's tile + the travelling rows of earlier tiles, then kick/drift
-template <bool FUSE>
+// ---------------------------------------------------------------------------
+// force_tiled3_f64 — one-sided 3-D kernel in double (one i per lane per register slot, like force_tiled_f64).
+// ---------------------------------------------------------------------------
+template <int P, bool GUARD, int UNROLL>
 __global__ __launch_bounds__(BLOCK)
-void sym_gather3(const float4 *__restrict__ slab_s, const float4 *__restrict__ slab_r,
-                 const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
-                 const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov, uint32_t n,
-                 float4 *__restrict__ acc_sum, const float4 *__restrict__ pos_cur, float4 *__restrict__ pos_next,
-                 float4 *__restrict__ vel, float4 *__restrict__ acc, float dt_kick, float dt_drift, int flags)
+void force_tiled3_f64(const double4 *__restrict__ pos, double4 *__restrict__ partial,
+                      uint32_t i_begin, uint32_t i_count, uint32_t j_begin, uint32_t j_end,
+                      uint32_t js, uint32_t i_tiles, double eps2, uint32_t gap_begin, uint32_t gap_len)
 {
-    __shared__ float4 part[GATHER_Q][GATHER_P];
+    constexpr uint32_t IT = BLOCK * P;
+    __shared__ double4 tile[2][TJ];
+    const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
+    if (!tm.valid) return;
+    const uint32_t t = threadIdx.x;
+    const uint32_t jn = j_end - j_begin;
+    const uint32_t slice_len = (((jn + js - 1) / js + TJ - 1) / TJ) * TJ;
+    const uint32_t s0 = j_begin + min(tm.slice * slice_len, jn);
+    const uint32_t s1 = j_begin + min((tm.slice + 1) * slice_len, jn);
+    double xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+    uint32_t li[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        li[p] = tm.i_tile * IT + (uint32_t)p * BLOCK + t;
+        const double4 p0 = pos[i_begin + min(li[p], i_count - 1)];
+        xi[p] = p0.x; yi[p] = p0.y; zi[p] = p0.z; ax[p] = ay[p] = az[p] = 0.0;
+    }
+    const uint32_t ntiles = (s1 - s0 + TJ - 1) / TJ;
+    const double4 none = make_double4(0.0, 0.0, 0.0, 0.0);        // mass 0: contributes nothing (eps > 0 or guarded)
+    {
+        const uint32_t j = s0 + t;
+        tile[0][t] = j < s1 ? pos[j + (j >= gap_begin ? gap_len : 0u)] : none;
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < ntiles; ++it) {
+        const uint32_t jn1 = s0 + (it + 1) * TJ + t;
+        const double4 qn = jn1 < s1 ? pos[jn1 + (jn1 >= gap_begin ? gap_len : 0u)] : none;
+        const double4 *__restrict__ cur = tile[it & 1];
+#pragma unroll UNROLL
+        for (int jj = 0; jj < TJ; ++jj) {
+            const double4 q = cur[jj];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const double dx = q.x - xi[p], dy = q.y - yi[p], dz = q.z - zi[p];
+                double r2, inv3;
+                if constexpr (GUARD) {
+                    r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2) : 0.0;
+                } else {
+                    r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+                    inv3 = rsqrt3_f64(r2);
+                }
+                const double sc = q.w * inv3;
+                ax[p] = __builtin_fma(sc, dx, ax[p]);
+                ay[p] = __builtin_fma(sc, dy, ay[p]);
+                az[p] = __builtin_fma(sc, dz, az[p]);
+            }
+        }
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = qn;
+        __syncthreads();
+    }
+    double4 *__restrict__ out = partial + (size_t)tm.slice * i_count;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (li[p] < i_count) out[li[p]] = make_double4(ax[p], ay[p], az[p], 0.0);
+}
+
+// ---------------------------------------------------------------------------
+// force_sym3_f64 — the symmetric scheme in 3-D double precision: same items, tiles and slabs as the other
+// symmetric kernels; a lane holds SYM_P64 = 8 stationary particles as scalars, the travelling particle (x, y, z
+// [, m]) and its accumulator rotate as pairs of 32-bit halves (12-14 ds_bpermute_b32 per step).
+// Body, both directions: 3 add + 3 fma + v_rsq_f64 + 6 (cube correction) + 6 fma (+2 mul with individual masses).
+// ---------------------------------------------------------------------------
+template <bool UM, bool DIAG>
+__device__ __forceinline__
+void sym3_chunks_f64(const double4 *__restrict__ pos, double4 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                     const double (&xi)[SYM_P64], const double (&yi)[SYM_P64], const double (&zi)[SYM_P64], const double (&mi)[SYM_P64],
+                     double (&ax)[SYM_P64], double (&ay)[SYM_P64], double (&az)[SYM_P64], double eps2, double um_mass,
+                     double4 (*red)[4][64])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    double xq = PAD_XY64, yq = PAD_XY64, zq = PAD_XY64, mq = 0.0;
+    {
+        const uint32_t j = c0 * SYM_CH + lane;
+        if (j < n) { const double4 pj = pos[j]; xq = pj.x; yq = pj.y; zq = pj.z; mq = pj.w; }
+    }
+    for (uint32_t c = 0; c < cnt; ++c) {
+        double xn = PAD_XY64, yn = PAD_XY64, zn = PAD_XY64, mn = 0.0;
+        {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (c + 1 < cnt && j < n) { const double4 pj = pos[j]; xn = pj.x; yn = pj.y; zn = pj.z; mn = pj.w; }
+        }
+        double aqx = 0.0, aqy = 0.0, aqz = 0.0;
+        for (int step = 0; step < 64; ++step) {
+            const double xr = lane_rot64(xq, addr), yr = lane_rot64(yq, addr), zr = lane_rot64(zq, addr);
+            double mr = 0.0;
+            if constexpr (!UM) mr = lane_rot64(mq, addr);
+#pragma unroll
+            for (int p = 0; p < SYM_P64; ++p) {
+                const double dx = xq - xi[p], dy = yq - yi[p], dz = zq - zi[p];
+                const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+                const double inv3 = rsqrt3_f64(r2);
+                double si = inv3, sj = inv3;
+                if constexpr (!UM) { si = mq * inv3; sj = mi[p] * inv3; }
+                ax[p] = __builtin_fma(si, dx, ax[p]);
+                ay[p] = __builtin_fma(si, dy, ay[p]);
+                az[p] = __builtin_fma(si, dz, az[p]);
+                if constexpr (!DIAG) {
+                    aqx = __builtin_fma(-sj, dx, aqx);
+                    aqy = __builtin_fma(-sj, dy, aqy);
+                    aqz = __builtin_fma(-sj, dz, aqz);
+                }
+            }
+            xq = xr; yq = yr; zq = zr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) { aqx = lane_rot64(aqx, addr); aqy = lane_rot64(aqy, addr); aqz = lane_rot64(aqz, addr); }
+        }
+        if constexpr (!DIAG) {
+            double4 r = make_double4(aqx, aqy, aqz, 0.0);
+            if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; r.z *= um_mass; }
+            double4 (*rb)[64] = red[c & 1u];
+            rb[w][lane] = r;
+            __syncthreads();
+            if (w == 0) {
+                const uint32_t j = (c0 + c) * SYM_CH + lane;
+                double4 a = rb[0][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; a.z += rb[k][lane].z; }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn; zq = zn;
+        if constexpr (!UM) mq = mn;
+    }
+}
+
+template <bool UM>
+__global__ __launch_bounds__(BLOCK)
+void force_sym3_f64(const double4 *__restrict__ pos, const SymItem *__restrict__ items,
+                    double4 *__restrict__ slab_s, double4 *__restrict__ slab_r, uint32_t n, double eps2, double um_mass)
+{
+    __shared__ double4 red[2][4][64];
+    const SymItem it = items[blockIdx.x];
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    double xi[SYM_P64], yi[SYM_P64], zi[SYM_P64], mi[SYM_P64], ax[SYM_P64], ay[SYM_P64], az[SYM_P64];
+    uint32_t li[SYM_P64];
+#pragma unroll
+    for (int p = 0; p < SYM_P64; ++p) {
+        li[p] = w * SYM_WT + (uint32_t)p * 64u + lane;
+        const uint32_t g = it.tile * SYM_SB + li[p];
+        xi[p] = yi[p] = zi[p] = PAD_XY64; mi[p] = 0.0;
+        if (g < n) { const double4 q = pos[g]; xi[p] = q.x; yi[p] = q.y; zi[p] = q.z; mi[p] = q.w; }
+        ax[p] = ay[p] = az[p] = 0.0;
+    }
+    double4 *__restrict__ rrow = slab_r + it.r_base;
+    if (it.diag) sym3_chunks_f64<UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    else         sym3_chunks_f64<UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    double4 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;
+#pragma unroll
+    for (int p = 0; p < SYM_P64; ++p) {
+        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; az[p] *= um_mass; }
+        out[li[p]] = make_double4(ax[p], ay[p], az[p], 0.0);
+    }
+}
+
+// sym_gather3 — the 3-D twin of sym_gather (nb_kernels.hip.h): sum of the stationary rows of particle k's tile +
+// the entries of its tile's coverage list, over particles [k0, k0 + kn); FUSE applies kick and drift (adding
+// `base`, the reduce-scattered sum of a sharded rank, when given), otherwise the sum is stored to acc_sum[k].
+template <typename real, bool FUSE>
+__global__ __launch_bounds__(BLOCK)
+void sym_gather3(const typename vec4_of<real>::type *__restrict__ slab_s, const typename vec4_of<real>::type *__restrict__ slab_r,
+                 const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
+                 const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov, uint32_t n, uint32_t k0, uint32_t kn,
+                 typename vec4_of<real>::type *__restrict__ acc_sum, const typename vec4_of<real>::type *__restrict__ base,
+                 const typename vec4_of<real>::type *__restrict__ pos_cur, typename vec4_of<real>::type *__restrict__ pos_next,
+                 typename vec4_of<real>::type *__restrict__ vel, typename vec4_of<real>::type *__restrict__ acc,
+                 real dt_kick, real dt_drift, int flags)
+{
+    typedef typename vec4_of<real>::type real4;
+    __shared__ real4 part[GATHER_Q][GATHER_P];
     const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
-    const uint32_t k = blockIdx.x * GATHER_P + p;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < n) {
+    const uint32_t li = blockIdx.x * GATHER_P + p, k = k0 + li;
+    real4 a = make_real4<real>(0, 0, 0, 0);
+    if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
         for (uint32_t r = row_lo[g] + q; r < row_hi[g]; r += GATHER_Q) {
-            const float4 b = slab_s[(size_t)r * SYM_SB + loc];
+            const real4 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
         const uint32_t c1 = cov_begin[g + 1];
         for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
             const SymCov cv = cov[i];
             if (k < cv.lo || k >= cv.hi) continue;
-            const float4 b = slab_r[cv.base + (int64_t)k];
+            const real4 b = slab_r[cv.base + (int64_t)k];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
     }
     part[q][p] = a;
     __syncthreads();
-    if (q == 0 && k < n) {
-        float4 s = part[0][p];
+    if (q == 0 && li < kn) {
+        real4 s = part[0][p];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { s.x += part[j][p].x; s.y += part[j][p].y; s.z += part[j][p].z; }
-        if constexpr (FUSE) kick_drift_one3(s, k, pos_cur, pos_next, vel, acc, 0u, dt_kick, dt_drift, flags);
-        else acc_sum[k] = s;
+        if (base) { const real4 b = base[li]; s.x += b.x; s.y += b.y; s.z += b.z; }
+        if constexpr (FUSE) kick_drift_one3<real>(s, li, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, flags);
+        else { s.w = 0; acc_sum[k] = s; }
     }
 }
 
 // ---------------------------------------------------------------------------
-// AoS (64-byte records, z in the first padding slot of pos / vel / acc) <-> SoA float4
+// AoS (64-byte records, z in the first padding slot of pos / vel / acc) <-> SoA real4
 // ---------------------------------------------------------------------------
+template <typename real>
 __global__ __launch_bounds__(BLOCK)
-void unpack_bodies3(const BodyRec *__restrict__ aos, uint32_t n, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                    float4 *__restrict__ acc, float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
+void unpack_bodies3(const BodyRec *__restrict__ aos, uint32_t n, typename vec4_of<real>::type *__restrict__ pos,
+                    typename vec4_of<real>::type *__restrict__ vel, typename vec4_of<real>::type *__restrict__ acc,
+                    float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float4 p = aos[i].q[0], m = aos[i].q[3];
-    pos[i] = make_float4(p.x, p.y, p.z, m.x);
+    pos[i] = make_real4<real>((real)p.x, (real)p.y, (real)p.z, (real)m.x);
     radius[i] = m.y;
     if (i >= i_begin && i - i_begin < i_count) {
         const float4 v = aos[i].q[1], a = aos[i].q[2];
-        vel[i - i_begin] = make_float4(v.x, v.y, v.z, 0.f);
-        acc[i - i_begin] = make_float4(a.x, a.y, a.z, 0.f);
+        vel[i - i_begin] = make_real4<real>((real)v.x, (real)v.y, (real)v.z, 0);
+        acc[i - i_begin] = make_real4<real>((real)a.x, (real)a.y, (real)a.z, 0);
     }
 }
 
+template <typename real>
 __global__ __launch_bounds__(BLOCK)
-void pack_bodies3(BodyRec *__restrict__ aos, const float4 *__restrict__ pos, const float4 *__restrict__ vel,
-                  const float4 *__restrict__ acc, const float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
+void pack_bodies3(BodyRec *__restrict__ aos, const typename vec4_of<real>::type *__restrict__ pos,
+                  const typename vec4_of<real>::type *__restrict__ vel, const typename vec4_of<real>::type *__restrict__ acc,
+                  const float *__restrict__ radius, uint32_t i_begin, uint32_t i_count)
 {
     const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
     if (li >= i_count) return;
-    const float4 p = pos[i_begin + li], v = vel[li], a = acc[li];
+    const auto p = pos[i_begin + li], v = vel[li], a = acc[li];
     BodyRec r;
-    r.q[0] = make_float4(p.x, p.y, p.z, 0.f);
-    r.q[1] = make_float4(v.x, v.y, v.z, 0.f);
-    r.q[2] = make_float4(a.x, a.y, a.z, 0.f);
-    r.q[3] = make_float4(p.w, radius[i_begin + li], 0.f, 0.f);
+    r.q[0] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
+    r.q[1] = make_float4((float)v.x, (float)v.y, (float)v.z, 0.f);
+    r.q[2] = make_float4((float)a.x, (float)a.y, (float)a.z, 0.f);
+    r.q[3] = make_float4((float)p.w, radius[i_begin + li], 0.f, 0.f);
     aos[li] = r;
 }
 
 // energy in fp64: K = sum m v^2 / 2, U = -1/2 sum_i m_i sum_{j != i} m_j / sqrt(r^2 + eps^2)
+template <typename real>
 __global__ __launch_bounds__(BLOCK)
-void energy_partials3(const float4 *__restrict__ pos, const float4 *__restrict__ vel, uint32_t n,
-                      uint32_t i_begin, uint32_t i_count, double eps2, double *__restrict__ ksum, double *__restrict__ usum)
+void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, const typename vec4_of<real>::type *__restrict__ vel,
+                      uint32_t n, uint32_t i_begin, uint32_t i_count, double eps2, double *__restrict__ ksum, double *__restrict__ usum)
 {
     struct alignas(16) JD { double x, y, z, m; };
     __shared__ JD tile[TJ];
@@ -362,13 +551,13 @@ void energy_partials3(const float4 *__restrict__ pos, const float4 *__restrict__
     const uint32_t t = threadIdx.x, li = blockIdx.x * BLOCK + t;
     const bool live = li < i_count;
     const uint32_t gi = i_begin + (live ? li : i_count - 1);
-    const float4 pi = pos[gi];
+    const auto pi = pos[gi];
     const double xi = pi.x, yi = pi.y, zi = pi.z;
     double u = 0.0;
     for (uint32_t j0 = 0; j0 < n; j0 += TJ) {
         const uint32_t j = j0 + t;
         __syncthreads();
-        if (j < n) { const float4 q = pos[j]; tile[t] = JD{(double)q.x, (double)q.y, (double)q.z, (double)q.w}; }
+        if (j < n) { const auto q = pos[j]; tile[t] = JD{(double)q.x, (double)q.y, (double)q.z, (double)q.w}; }
         else tile[t] = JD{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
         const uint32_t cnt = min((uint32_t)TJ, n - j0);
@@ -382,7 +571,7 @@ void energy_partials3(const float4 *__restrict__ pos, const float4 *__restrict__
     double k = 0.0, uu = 0.0;
     if (live) {
         const double m = (double)pi.w;
-        const float4 v = vel[li];
+        const auto v = vel[li];
         k = 0.5 * m * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
         uu = -0.5 * m * u;
     }

@@ -179,6 +179,7 @@ class DistributedSimulation:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self._dtype = torch.float64 if precision == "fp64" else torch.float32
+        self._width = 4 if int(sim_kwargs.get("dims", 2)) == 3 else 2     # (x, y) or (x, y, z, m) per particle
         self._args = dict(eps=eps, precision=precision, rsqrt=rsqrt, order=order, j_slices=j_slices, **sim_kwargs)
         self._device_index = device_index
         self.stream = torch.cuda.Stream(self.device)
@@ -209,13 +210,13 @@ class DistributedSimulation:
         self.sim = None
         try:
             # full-n position replicas owned by torch so the collective can write them
-            self.pos = [torch.empty((self.plan.n, 2), dtype=self._dtype, device=self.device) for _ in range(2)]
+            self.pos = [torch.empty((self.plan.n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
             # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
             self.acc_full = self.acc_owned = None
             acc_ptrs = None
             if world > 1 and protocol != "allgather":
-                self.acc_full = torch.zeros((self.plan.n, 2), dtype=self._dtype, device=self.device)
-                self.acc_owned = torch.zeros((self.plan.i_count, 2), dtype=self._dtype, device=self.device)
+                self.acc_full = torch.zeros((self.plan.n, self._width), dtype=self._dtype, device=self.device)
+                self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
                 acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
             kw = dict(self._args)
             if protocol == "allgather":

@@ -1,8 +1,9 @@
 """GPU: the 3-D build extension.  z lives in the padding float that follows y in the
 reference's alignas(16) Vec2, sizeof(Body) stays 64.  The reference has no 3-D arithmetic, so the
 oracle here is the fp64 restatement with a z term ("parity unpinned"); bars: <= 1e-5 relative on
-positions / velocities, planar data reproduces the 2-D path, symmetric == one-sided."""
-import os
+positions / velocities (fp32), total energy to 1e-10 (fp64), planar data reproduces the 2-D path,
+symmetric == one-sided, sharded (both protocols, fp32 and fp64) == unsharded."""
+import ctypes
 
 import numpy as np
 import pytest
@@ -10,6 +11,7 @@ import pytest
 from conftest import max_rel
 
 import nbodysim_amd as nb
+from nbodysim_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -82,10 +84,90 @@ def test_3d_dump_keeps_z_and_2d_dump_zeroes_padding(tmp_path):
 
 
 def test_3d_rejects_unsupported_combinations():
+    """The reference defines its sequential order and iterate()'s extras in the plane only."""
     ic = nb.plummer_3d(1000, 1)
-    for kw in (dict(precision="fp64"), dict(order="sequential"), dict(extras=1), dict(i_begin=0, i_count=500)):
-        with pytest.raises(nb.NBodyError):
+    for kw in (dict(order="sequential"), dict(extras=1), dict(precision="fp64", rsqrt="quake")):
+        with pytest.raises(nb.NBodyError) as e:
             nb.Simulation(ic, dims=3, **kw)
+        assert e.value.code == L.NB_EINVAL
+
+
+@pytest.mark.parametrize("n,steps", [(3000, 6), (20000, 3), (40001, 2)])
+@pytest.mark.parametrize("masses", ["uniform", "individual"])
+def test_3d_fp64_matches_fp64_restatement(nbo, n, steps, masses):
+    """force_sym3_f64 / force_tiled3_f64: the same trajectory as the CPU fp64 direct sum with a z term."""
+    ic = nb.plummer_3d(n, 21).view(nb.BODY3_DTYPE)
+    if masses == "individual":
+        ic["mass"] = (np.random.default_rng(n).uniform(0.5, 1.5, n) / n).astype(np.float32)
+    st = nbo.state3_from_bodies(ic)
+    e0 = sum(nbo.energy3(st, f32(0.03)))
+    nbo.step3_f64(st, f32(0.03), f32(1e-3), steps)
+    e1 = sum(nbo.energy3(st, f32(0.03)))
+    for symm in (True, False):
+        with nb.Simulation(ic, eps=0.03, dims=3, precision="fp64", symmetry=symm) as sim:
+            assert "fp64 3-D" in sim.describe() and f"symmetric={int(symm and n >= 16384)}" in sim.describe()
+            k0, u0 = sim.energy()
+            sim.advance(steps, 1e-3)
+            k1, u1 = sim.energy()
+            got = sim.sync()
+        assert abs(k0 + u0 - e0) < 1e-12 * abs(e0)
+        assert abs(k1 + u1 - e1) < 1e-10 * abs(e1), (symm, (k1 + u1 - e1) / e1)
+        assert max_rel(got["pos"], np.stack([st["x"], st["y"], st["z"]], 1)) < 2e-7        # float output records
+        assert max_rel(got["vel"], np.stack([st["vx"], st["vy"], st["vz"]], 1)) < 2e-7
+        a64 = np.stack([st["ax"], st["ay"], st["az"]], 1)
+        assert np.max(np.abs(got["acc"] - a64)) < 2e-7 * np.max(np.abs(a64))
+
+
+def _run_sharded3(ic, parts, steps, dt, **kw):
+    """P handles of a 3-D system on one GPU, driven from this process through the library's in-process exchanges."""
+    lib = nb.load()
+    n = ic.shape[0]
+    blk = n // parts
+    sims = [nb.Simulation(ic, dims=3, i_begin=r * blk, i_count=blk, shard_rank=r, shard_world=parts, **kw) for r in range(parts)]
+    try:
+        protos = {s.shard_protocol for s in sims}
+        assert len(protos) == 1
+        sym = protos == {L.NB_SHARD_SYMMETRIC}
+        handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
+        for _ in range(steps):
+            for s in sims:
+                s.step_begin(dt)
+            if sym:
+                for s in sims:
+                    s.step_mid()
+                L.check("nb_exchange_accelerations", lib.nb_exchange_accelerations(handles, parts))
+            for s in sims:
+                s.step_finish()
+            L.check("nb_exchange_positions", lib.nb_exchange_positions(handles, parts))
+        out = nb.bodies_array(n).view(nb.BODY3_DTYPE)
+        k = u = 0.0
+        for s in sims:
+            out[s.i_begin:s.i_begin + s.i_count] = s.sync()
+            kk, uu = s.energy()
+            k, u = k + kk, u + uu
+    finally:
+        for s in sims:
+            s.close()
+    return out, k + u, sym
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("protocol,parts,late_us", [("symmetric", 2, -1.0), ("symmetric", 4, 40.0), ("allgather", 4, 0.0)])
+def test_3d_sharded_handles_match_unsharded(precision, protocol, parts, late_us):
+    n, steps = 65536, 3
+    ic = nb.plummer_3d(n, 9).view(nb.BODY3_DTYPE)
+    kw = dict(eps=0.02, precision=precision, symmetry=protocol == "symmetric", sym_late_us=late_us)
+    with nb.Simulation(ic, dims=3, eps=0.02, precision=precision) as sim:
+        sim.advance(steps, 1e-3)
+        whole = sim.sync().copy()
+        e_whole = sum(sim.energy())
+    out, e, sym = _run_sharded3(ic, parts, steps, 1e-3, **kw)
+    assert sym == (protocol == "symmetric")
+    tol_p, tol_v = (2e-6, 2e-5) if precision == "fp32" else (2e-7, 2e-7)
+    assert max_rel(out["pos"], whole["pos"]) < tol_p and max_rel(out["vel"], whole["vel"]) < tol_v
+    assert np.max(np.abs(out["acc"] - whole["acc"])) < (2e-5 if precision == "fp32" else 2e-7) * np.max(np.abs(whole["acc"]))
+    assert abs(e - e_whole) < (1e-5 if precision == "fp32" else 1e-10) * abs(e_whole)
+    assert out["pos"][:, 2].any()
 
 
 def test_3d_kdk_integrator_matches_numpy_leapfrog(nbo):

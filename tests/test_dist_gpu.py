@@ -155,3 +155,66 @@ def test_held_back_local_items_give_the_same_trajectory(tmp_path, world, precisi
         assert int(flags[0]) == 1 and int(flags[1]) == 1          # symmetric protocol, late items present
     tol = 2e-6 if precision == "fp32" else 1e-7
     assert _rel(pos, pos_ref) < tol and _rel(vel, vel_ref) < 10 * tol
+
+
+def _tune_worker(rank, world, port, n, dims, precision, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import json
+
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd.dist import DistributedSimulation
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ic = nb.plummer_2d(n, 42) if dims == 2 else nb.plummer_3d(n, 42)
+        sim = DistributedSimulation(ic, eps=0.05, precision=precision, device_index=0, protocol="tune", tune_steps=3, dims=dims)
+        assert sim.frame == 0 and sim.tuning is not None and sim.tuning["chosen"] == sim.protocol      # tuned on a scratch copy
+        sim.profile_phases(True)
+        sim.advance(4, 1e-3)
+        rep = sim.phase_report()
+        mine = sim.sync().copy()
+        assert sim.frame == 4
+        np.save(Path(out_dir) / f"tpos_{rank}.npy", mine["pos"])
+        (Path(out_dir) / f"tune_{rank}.json").write_text(json.dumps({"tuning": sim.tuning, "phases": rep, "protocol": sim.protocol}))
+        # a forced protocol the system is not eligible for fails on EVERY rank (no rank is left waiting in a collective)
+        try:
+            DistributedSimulation(nb.plummer_2d(4096, 1), eps=0.05, device_index=0, protocol="symmetric")
+            raise AssertionError("symmetric protocol accepted for a 4096-body system")
+        except RuntimeError as e:
+            assert "not eligible" in str(e)
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,dims,precision", [(32768, 2, "fp32"), (32768, 3, "fp32"), (16384, 3, "fp64")])
+def test_protocol_autotune_and_phase_report_two_ranks(tmp_path, n, dims, precision):
+    """protocol="tune": both exchange protocols are timed on a scratch copy, the ranks agree on one, the run proper
+    starts from frame 0 with it; the per-phase event report carries every phase of that protocol (2-D and 3-D)."""
+    import json
+
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_tune_worker, args=(world, _free_port(), n, dims, precision, str(tmp_path)), nprocs=world, join=True)
+    reps = [json.loads((tmp_path / f"tune_{r}.json").read_text()) for r in range(world)]
+    assert reps[0]["tuning"] == reps[1]["tuning"] and reps[0]["protocol"] == reps[1]["protocol"]
+    t = reps[0]["tuning"]
+    assert set(t["ms_per_step"]) == {"symmetric", "allgather"} and all(0 < v < 1e4 for v in t["ms_per_step"].values())
+    want = ("local", "ag_wait", "cross", "reduce_scatter", "finish") if reps[0]["protocol"] == "symmetric" else ("local", "ag_wait", "remote_finish")
+    for r in reps:
+        assert r["phases"]["steps"] == 4 and all(k in r["phases"] and r["phases"][k] >= 0 for k in want)
+        assert r["phases"]["host_enqueue"] > 0 and r["phases"]["stream_total"] > 0
+    import nbodysim_amd as nb
+    ic = nb.plummer_2d(n, 42) if dims == 2 else nb.plummer_3d(n, 42).view(nb.BODY3_DTYPE)
+    with nb.Simulation(ic, eps=0.05, precision=precision, dims=dims) as sim:
+        sim.advance(4, 1e-3)
+        ref = sim.sync()["pos"].astype(np.float64)
+    pos = np.concatenate([np.load(tmp_path / f"tpos_{r}.npy") for r in range(world)])
+    assert _rel(pos.reshape(n, -1)[:, :dims], ref.reshape(n, -1)[:, :dims]) < (2e-6 if precision == "fp32" else 1e-7)

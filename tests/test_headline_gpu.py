@@ -10,7 +10,8 @@ CPU oracle — not against another GPU kernel and not through a property that ho
             for one tile, against FP64-DIRECT.
   config 5  N = 262 144 fp64: one handle and the 8-way split; total energy after two steps against the CPU fp64
             direct sum (nbo.step_f64 + nbo.energy) to 1e-10, drift reported.
-Tolerances (north_star): positions / velocities 1e-5 relative; accelerations 2e-5 of the force scale max|a|.
+Tolerances (north_star): positions / velocities 1e-5 relative; accelerations 2e-5 of the force scale (the largest
+acceleration component of the system, as in the other symmetric-kernel tests).
 """
 import ctypes
 
@@ -60,12 +61,12 @@ def test_headline_kernel_accelerations_and_two_steps_vs_fp64_direct(headline_ic,
         two = sim.sync().copy()
     st0 = nbo.state_from_bodies(ic, np.float64)
     st1 = oracle_step1
-    scale = None
+    scale = np.max(np.abs(np.stack([st1["ax"], st1["ay"]], 1)))          # force scale: oracle accelerations at x_0, all particles
     for lo, hi in slices_of(N):
         ax, ay = nbo.accel_f64(st0, f32(EPS), lo, hi)
         ref = np.stack([ax[lo:hi], ay[lo:hi]], 1)
-        scale = max(scale or 0.0, np.max(np.abs(ref)))
-        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * scale, (lo, hi)
+        assert np.median(np.abs(acc[lo:hi] - ref) / np.abs(ref)) < 2e-6, (lo, hi)           # typical particle: ~1e-7
         # step 1 of the oracle (all particles) == acc above; step 2 needs the slice's acceleration at x_1 only
         bx, by = nbo.accel_f64(st1, f32(EPS), lo, hi)
         v2 = np.stack([st1["vx"][lo:hi] + bx[lo:hi] * f32(DT), st1["vy"][lo:hi] + by[lo:hi] * f32(DT)], 1)
@@ -77,20 +78,17 @@ def test_headline_kernel_accelerations_and_two_steps_vs_fp64_direct(headline_ic,
         one = sim.sync()
     assert max_rel(one["pos"], np.stack([st1["x"], st1["y"]], 1)) < 1e-5
     assert max_rel(one["vel"], np.stack([st1["vx"], st1["vy"]], 1)) < 1e-5
-    assert np.max(np.abs(one["acc"].astype(np.float64) - np.stack([st1["ax"], st1["ay"]], 1))) < 2e-5 * np.max(np.abs(st1["ax"]))
+    assert np.max(np.abs(one["acc"].astype(np.float64) - np.stack([st1["ax"], st1["ay"]], 1))) < 2e-5 * scale
 
 
-def test_headline_kernel_general_masses_vs_fp64_direct(headline_ic, nbo):
+def test_headline_kernel_general_masses_vs_fp64_direct(headline_ic, oracle_step1, nbo):
     """The same plan without the equal-mass specialisation (12 + 2 instead of 10 + 2 ops per body)."""
     ic = headline_ic
     with nb.Simulation(ic, eps=EPS, uniform_mass=False) as sim:
         assert "symmetric=1" in sim.describe() and "uniform_mass=0" in sim.describe()
         acc = sim.accelerations().astype(np.float64)
-    st0 = nbo.state_from_bodies(ic, np.float64)
-    for lo, hi in slices_of(N):
-        ax, ay = nbo.accel_f64(st0, f32(EPS), lo, hi)
-        ref = np.stack([ax[lo:hi], ay[lo:hi]], 1)
-        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+    ref = np.stack([oracle_step1["ax"], oracle_step1["ay"]], 1)          # the oracle's accelerations at x_0, EVERY particle
+    assert np.max(np.abs(acc - ref)) < 2e-5 * np.max(np.abs(ref))
 
 
 def test_headline_kernel_quake_mode_vs_reference_arithmetic(headline_ic, nbo):
@@ -101,10 +99,14 @@ def test_headline_kernel_quake_mode_vs_reference_arithmetic(headline_ic, nbo):
         assert "symmetric=1" in sim.describe()
         acc = sim.accelerations().astype(np.float64)
     st = nbo.state_from_bodies(ic)
+    scale = np.max(np.abs(acc))
     for lo, hi in slices_of(N):
+        # the reference sums 262 144 fp32 terms in one running sum: its own rounding (~1e-5 of a typical term sum)
+        # is part of this difference, which is why the bar is on the force scale
         ax, ay = nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, lo, hi)
         ref = np.stack([ax[lo:hi], ay[lo:hi]], 1).astype(np.float64)
-        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * np.max(np.abs(ref)), (lo, hi)
+        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * scale, (lo, hi)
+        assert np.median(np.abs(acc[lo:hi] - ref) / np.abs(ref)) < 1e-5, (lo, hi)
 
 
 @pytest.mark.parametrize("n,steps", [(16384, 10), (32768, 4)])

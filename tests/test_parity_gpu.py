@@ -608,11 +608,12 @@ def test_reference_full_default_start_through_the_gpu_path(nbo):
 
 
 def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
-    """Index arithmetic far beyond the BASELINE sizes: a handle that owns the LAST 4096 + 77 particles of
-    n = 4 194 381 (ragged: not a multiple of any tile) computes their accelerations from all n bodies; the CPU
-    fp64 direct sum over the same i-range (1.7e10 pairs) is the check.  Also the symmetric path's 48 GiB slab cap:
-    a whole-system handle of this size must choose the one-sided kernel."""
-    n, own = (1 << 22) + 77, 4096 + 77
+    """Index arithmetic far beyond the BASELINE sizes, n = 4 294 381 (ragged: not a multiple of any tile).
+    (a) a handle that owns the LAST 4096 + 77 particles computes their accelerations from all n bodies with the
+    one-sided kernel; (b) a whole-system handle runs the symmetric kernel over 32 GiB of travelling partials
+    (4.4e9 slab elements: 64-bit offsets, sized for the 288 GB of an MI355X).  The CPU fp64 direct sum over the same
+    i-range (1.7e10 pairs) is the check for both."""
+    n, own = (1 << 22) + 100077, 4096 + 77
     ic = nb.plummer_2d(n, 3)
     with nb.Simulation(ic, eps=0.01, i_begin=n - own, i_count=own) as sim:
         assert sim.shard_protocol == L.NB_SHARD_ALLGATHER
@@ -629,7 +630,25 @@ def test_four_million_bodies_last_block_against_the_fp64_direct_sum(nbo):
     x1 = ic["pos"][n - own:].astype(np.float64) + v1 * 1e-3
     assert max_rel(got["vel"], v1) < 1e-5 and max_rel(got["pos"], x1) < 1e-6
     with nb.Simulation(ic, eps=0.01) as sim:
-        assert "symmetric=0" in sim.describe()          # 2049 travelling rows x n x 8 B = 64 GiB > cap
+        info = sim.sym_info()
+        assert info["enabled"] == 1 and 33 * 2**30 < info["slab_r_bytes"] < 34 * 2**30 and info["slab_r_bytes"] // 8 > 2**32
+        sim.advance(1, 1e-3)
+        whole = sim.sync()
+    wacc = whole["acc"][n - own:].astype(np.float64)
+    assert np.max(np.abs(wacc - ref)) < 2e-5 * np.max(np.abs(ref))
+    assert max_rel(whole["vel"][n - own:], v1) < 1e-5 and max_rel(whole["pos"][n - own:], x1) < 1e-6
+    m = ic["mass"].astype(np.float64)[:, None]
+    f = (m * whole["acc"].astype(np.float64)).sum(0)
+    assert (np.abs(f) < 1e-5 * np.abs(m * whole["acc"]).sum(0)).all()
+
+
+def test_symmetric_path_memory_cap_falls_back_to_the_one_sided_kernel():
+    """Beyond the 96-GiB bound on the travelling partials (tiles x n / 2 elements: n ~ 7 million fp32) a whole-system
+    handle chooses the one-sided kernel by itself: n = 8 388 608 would need 128 GiB."""
+    n = 1 << 23
+    ic = nb.plummer_2d(n, 3)
+    with nb.Simulation(ic, eps=0.01) as sim:
+        assert "symmetric=0" in sim.describe() and sim.sym_info()["enabled"] == 0
 
 
 def test_two_million_bodies_symmetric_kernel_properties():

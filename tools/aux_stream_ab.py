@@ -10,9 +10,9 @@ ic = nb.plummer_2d(n, 42)
 for parts in (2, 4, 8):
     for rep in range(3):
         for aux in (0, 1):
-            os.environ["NB_SYM_AUX_STREAM"] = str(aux)
             rank = parts // 2
-            with nb.Simulation(ic, eps=0.01, i_begin=rank * (n // parts), i_count=n // parts, shard_rank=rank, shard_world=parts) as sim:
+            with nb.Simulation(ic, eps=0.01, i_begin=rank * (n // parts), i_count=n // parts, shard_rank=rank, shard_world=parts,
+                               sym_aux_stream=1 if aux else -1) as sim:
                 def go(k):
                     for _ in range(k): sim.step_begin(1e-3); sim.step_mid(); sim.step_finish()
                 go(5); sim.wait()

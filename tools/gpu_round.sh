@@ -17,6 +17,7 @@ stage() {  # stage <seconds> <logfile> <cmd...>
 for what in "$@"; do
   case $what in
     tests)  stage 900 gpurun_out/test_gpu.log python -m pytest tests -m gpu -x -q --durations=8; tail -15 gpurun_out/test_gpu.log ;;
+    testsall) stage 1100 gpurun_out/test_gpu.log python -m pytest tests -m gpu -q --durations=12; tail -40 gpurun_out/test_gpu.log ;;
     smoke)  stage 300 gpurun_out/smoke.log python -c "import __graft_entry__ as g; g.smoke()"; tail -3 gpurun_out/smoke.log ;;
     bench)  stage 600 gpurun_out/bench.log python bench.py --steps 20 --warmup 3; tail -2 gpurun_out/bench.log ;;
     benchq) stage 300 gpurun_out/bench.log python bench.py --steps 20 --warmup 3 --no-cpu-baseline; tail -2 gpurun_out/bench.log ;;
@@ -25,6 +26,11 @@ for what in "$@"; do
             rm -rf gpurun_out/prof
             stage 600 gpurun_out/rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
             tail -3 gpurun_out/rocprof_stats.log; find gpurun_out/prof -name '*stats*' | head ;;
+    prof64) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+            rm -rf gpurun_out/prof64
+            stage 600 gpurun_out/rocprof_stats64.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof64 -- python3 bench.py --precision fp64 --steps 10 --warmup 2 --no-cpu-baseline
+            tail -3 gpurun_out/rocprof_stats64.log; find gpurun_out/prof64 -name '*stats*' | head ;;
+    bench64) stage 300 gpurun_out/bench64.log python bench.py --precision fp64 --steps 20 --warmup 3 --no-cpu-baseline; tail -1 gpurun_out/bench64.log ;;
     pmc)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
             rm -rf gpurun_out/pmc
             for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY" \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the guided tail (finer items at the end of a launch) on one GPU: whole system and one rank's share.
-NB_SYM_NO_GUIDED_TAIL=1 is the uniform plan; NB_SYM_TAIL="a,b,c" sets the work fractions where items shrink to L/2, L/4, L/8."""
+guided_tail=False (NB_FLAG_NO_GUIDED_TAIL) is the uniform plan; sym_tail=(a, b, c) sets the work fractions where items shrink to L/2, L/4, L/8."""
 import os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -14,11 +14,10 @@ ic = nb.plummer_2d(n, 42)
 for parts in (1, 2, 8):
     for rep in range(2):
         for name, tail in VARIANTS:
-            os.environ.pop("NB_SYM_NO_GUIDED_TAIL", None); os.environ.pop("NB_SYM_TAIL", None)
-            if tail is None: os.environ["NB_SYM_NO_GUIDED_TAIL"] = "1"
-            elif tail: os.environ["NB_SYM_TAIL"] = tail
             rank = parts // 2
             kw = dict(i_begin=rank * (n // parts), i_count=n // parts, shard_rank=rank, shard_world=parts) if parts > 1 else {}
+            if tail is None: kw["guided_tail"] = False
+            elif tail: kw["sym_tail"] = tuple(float(x) for x in tail.split(","))
             with nb.Simulation(ic, eps=0.01, **kw) as sim:
                 def go(k):
                     if parts == 1: sim.advance(k, 1e-3)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B on one GPU of holding back NB_SYM_LATE_US microseconds of local items for the side stream.  Without a
+"""A/B on one GPU of holding back nb_params.sym_late_us microseconds of local items for the side stream.  Without a
 transport there is no reduce-scatter to hide, so this measures only what the split costs (wall ms/step)."""
 import os, sys, time
 from pathlib import Path
@@ -12,10 +12,9 @@ for precision in ("fp32", "fp64"):
     for parts in (2, 4, 8):
         for rep in range(2):
             for us in (0, 40):
-                os.environ["NB_SYM_LATE_US"] = str(us)
                 rank = parts // 2
                 with nb.Simulation(ic, eps=0.01, precision=precision, i_begin=rank * (n // parts), i_count=n // parts,
-                                   shard_rank=rank, shard_world=parts) as sim:
+                                   shard_rank=rank, shard_world=parts, sym_late_us=float(us) if us else -1.0) as sim:
                     def go(k):
                         for _ in range(k): sim.step_begin(1e-3); sim.step_mid(); sim.step_finish()
                     go(5); sim.wait()

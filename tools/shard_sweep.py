@@ -13,8 +13,7 @@ icount = n // parts
 res = []
 for P in ("4", "2", "1"):
     for js in (0, 56, 64, 112, 128, 224, 256, 448, 896):
-        os.environ["NB_FORCE_P"] = P
-        with nb.Simulation(ic, eps=0.01, i_begin=rank * icount, i_count=icount, j_slices=js) as sim:
+        with nb.Simulation(ic, eps=0.01, i_begin=rank * icount, i_count=icount, j_slices=js, lanes_p=int(P), symmetry=False) as sim:
             for _ in range(3):
                 sim.step_begin(1e-3); sim.step_finish()
             sim.wait(); sim.profile(True)

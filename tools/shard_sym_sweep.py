@@ -9,11 +9,9 @@ n, steps = 262144, 40
 ic = nb.plummer_2d(n, 42)
 for parts in (8, 4, 2, 1):
     for L in (0, 2, 4, 8, 16, 32, 64):
-        if L: os.environ["NB_SYM_L"] = str(L)
-        else: os.environ.pop("NB_SYM_L", None)
         rank = parts // 2
         kw = dict(i_begin=rank * (n // parts), i_count=n // parts, shard_rank=rank, shard_world=parts) if parts > 1 else {}
-        with nb.Simulation(ic, eps=0.01, **kw) as sim:
+        with nb.Simulation(ic, eps=0.01, sym_chunks_per_item=L, **kw) as sim:
             def go(k):
                 if parts == 1: sim.advance(k, 1e-3)
                 else:

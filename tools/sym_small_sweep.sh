@@ -3,8 +3,7 @@
 for n in 16384 25000 32768 65536 131072; do
  for L in 0 1 2 3 4 6 8 12 16; do
   echo -n "n=$n L=$L: "
-  if [ $L -eq 0 ]; then unset NB_SYM_L; else export NB_SYM_L=$L; fi
-  python bench.py --n $n --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --n $n --chunks-per-item $L --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); print(round(d['ms_per_step']*1000,1),'us/step kernel', round(d['roofline']['avg_launch_ms']*1000,1), d['config']['launch'].split('|')[-2])"
  done
