@@ -117,6 +117,36 @@ void nbo_accel_f32(size_t n, const float *x, const float *y, const float *m,
     }
 }
 
+/* The reference's per-pair TERMS (every operation in fp32, Quake or exact rsqrt, exactly as above) summed in
+ * double instead of the reference's single fp32 running sum: what Quadtree.hpp:134-144 would return without its
+ * own summation rounding (which grows ~ sqrt(n) * 6e-8 and reaches ~2e-5 of the force at n = 262 144).  Used to
+ * tell a kernel's error from the reference's own noise at large n; not a reference result in itself. */
+void nbo_accel_f32_terms_acc64(size_t n, const float *x, const float *y, const float *m,
+                               float eps2, int rsqrt_mode, size_t i_begin, size_t i_end,
+                               double *ax, double *ay)
+{
+    if (i_end <= i_begin) return;
+    const int nt = nbo_get_threads();
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = (long)i_begin; i < (long)i_end; ++i) {
+        const float xi = x[i], yi = y[i];
+        double sx = 0.0, sy = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            const float rx = x[j] - xi, ry = y[j] - yi;
+            const float r_sq = rx * rx + ry * ry;
+            if (r_sq > 0) {
+                const float inv = rsqrt_mode == NBO_RSQRT_QUAKE ? quake_rsqrt(r_sq + eps2) : RSQ_EXACT_F32(r_sq + eps2);
+                const float inv3 = inv * inv * inv;
+                const float s = m[j] * inv3;
+                const float cx = rx * s, cy = ry * s;
+                sx += (double)cx; sy += (double)cy;
+            }
+        }
+        ax[i] = sx; ay[i] = sy;
+    }
+}
+
 void nbo_accel_f64(size_t n, const double *x, const double *y, const double *m,
                    double eps2, size_t i_begin, size_t i_end,
                    double *ax, double *ay)

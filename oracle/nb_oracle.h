@@ -42,6 +42,10 @@ void nbo_accel_f32(size_t n, const float *x, const float *y, const float *m,
 void nbo_accel_f64(size_t n, const double *x, const double *y, const double *m,
                    double eps2, size_t i_begin, size_t i_end,
                    double *ax, double *ay);
+/* the reference's fp32 per-pair terms summed in double (its arithmetic without its summation rounding) */
+void nbo_accel_f32_terms_acc64(size_t n, const float *x, const float *y, const float *m,
+                               float eps2, int rsqrt_mode, size_t i_begin, size_t i_end,
+                               double *ax, double *ay);
 
 /* nsteps of: accel; v += a*dt; x += v*dt  (Simulation.hpp:117,129-131,160-163).
  * extras != 0 also applies the velocity clamp and the soft boundary of

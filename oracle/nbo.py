@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         l.nbo_get_threads.restype = C.c_int
         l.nbo_accel_f32.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_size_t, C.c_size_t, _f32p, _f32p]
         l.nbo_accel_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, C.c_double, C.c_size_t, C.c_size_t, _f64p, _f64p]
+        l.nbo_accel_f32_terms_acc64.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_size_t, C.c_size_t, _f64p, _f64p]
         l.nbo_step_f32.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         l.nbo_step_f64.argtypes = [C.c_size_t, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
         l.nbo_kick_drift_f32.argtypes = [C.c_size_t, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int]
@@ -148,6 +149,18 @@ def accel_f32(st: dict, eps: float, rsqrt: int, i_begin: int = 0, i_end: int | N
     ay = np.zeros(n, np.float32)
     eps2 = np.float32(eps) * np.float32(eps)
     lib().nbo_accel_f32(n, st["x"], st["y"], st["m"], eps2, rsqrt, i_begin, i_end, ax, ay)
+    return ax, ay
+
+
+def accel_f32_terms_acc64(st: dict, eps: float, rsqrt: int, i_begin: int = 0, i_end: int | None = None):
+    """The reference's fp32 per-pair terms (Quadtree.hpp:136-143) summed in double: its arithmetic without the
+    rounding of its single fp32 running sum."""
+    n = st["x"].shape[0]
+    i_end = n if i_end is None else i_end
+    ax = np.zeros(n, np.float64)
+    ay = np.zeros(n, np.float64)
+    eps2 = np.float32(eps) * np.float32(eps)
+    lib().nbo_accel_f32_terms_acc64(n, st["x"], st["y"], st["m"], eps2, rsqrt, i_begin, i_end, ax, ay)
     return ax, ay
 
 

@@ -93,7 +93,11 @@ def test_headline_kernel_general_masses_vs_fp64_direct(headline_ic, oracle_step1
 
 def test_headline_kernel_quake_mode_vs_reference_arithmetic(headline_ic, nbo):
     """rsqrt = quake on the symmetric kernel against the reference's own pairwise arithmetic (fast_inv_sqrt,
-    fp32, j ascending — Quadtree.hpp:106-111,134-144) at the headline size."""
+    fp32 terms — Quadtree.hpp:106-111,134-144) at the headline size.  The reference adds 262 144 fp32 terms into ONE
+    fp32 running sum, whose own rounding reaches ~2e-5 of the force scale here; so the kernel is held
+    (a) to 1e-5 of the force scale against the reference's terms summed in double (its arithmetic without its
+        summation noise), and must be CLOSER to that than the reference's fp32 sum is, and
+    (b) to 4e-5 against the reference's fp32 sum itself (bit-exact with the compiled reference, tests/test_oracle.py)."""
     ic = headline_ic
     with nb.Simulation(ic, eps=EPS, rsqrt="quake") as sim:
         assert "symmetric=1" in sim.describe()
@@ -101,12 +105,15 @@ def test_headline_kernel_quake_mode_vs_reference_arithmetic(headline_ic, nbo):
     st = nbo.state_from_bodies(ic)
     scale = np.max(np.abs(acc))
     for lo, hi in slices_of(N):
-        # the reference sums 262 144 fp32 terms in one running sum: its own rounding (~1e-5 of a typical term sum)
-        # is part of this difference, which is why the bar is on the force scale
         ax, ay = nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, lo, hi)
-        ref = np.stack([ax[lo:hi], ay[lo:hi]], 1).astype(np.float64)
-        assert np.max(np.abs(acc[lo:hi] - ref)) < 2e-5 * scale, (lo, hi)
-        assert np.median(np.abs(acc[lo:hi] - ref) / np.abs(ref)) < 1e-5, (lo, hi)
+        ref32 = np.stack([ax[lo:hi], ay[lo:hi]], 1).astype(np.float64)
+        bx, by = nbo.accel_f32_terms_acc64(st, EPS, nbo.RSQRT_QUAKE, lo, hi)
+        ref = np.stack([bx[lo:hi], by[lo:hi]], 1)
+        err_gpu, err_ref = np.max(np.abs(acc[lo:hi] - ref)), np.max(np.abs(ref32 - ref))
+        assert err_gpu < 1e-5 * scale, (lo, hi, err_gpu / scale)
+        assert err_gpu < err_ref, (lo, hi, err_gpu, err_ref)             # the tiled partial sums round less than one running sum
+        assert np.max(np.abs(acc[lo:hi] - ref32)) < 4e-5 * scale, (lo, hi)
+        assert np.median(np.abs(acc[lo:hi] - ref32) / np.abs(ref32)) < 1e-5, (lo, hi)
 
 
 @pytest.mark.parametrize("n,steps", [(16384, 10), (32768, 4)])
