@@ -189,6 +189,15 @@ int nb_host_unregister(void *ptr);
  * For NB_FP64 handles values are rounded to float. */
 int nb_sync_positions(nb_sim *s, float *out_xy);
 
+/* Pipelined snapshot for a caller that does `step(); copy bodies` every frame (main.cpp:621-627) and can take the
+ * copy one step late: nb_snapshot_begin packs the owned block as of the work enqueued so far and starts its D2H
+ * copy on a separate copy stream, then returns; steps enqueued afterwards run concurrently with the transfer
+ * (16.8 MB per frame at N = 262 144).  nb_snapshot_wait blocks until `out` is complete.  One snapshot in flight
+ * per handle; `out` should be page-locked (nb_host_register) — otherwise the data lands in the library's staging
+ * buffer and is copied to `out` inside nb_snapshot_wait.  nb_sync stays the simple blocking form. */
+int nb_snapshot_begin(nb_sim *s, nb_body *out);
+int nb_snapshot_wait(nb_sim *s);
+
 /* Push host-side edits of the bodies back (the reference's `bodies` is public
  * and the GUI appends to it through SPAWN_QUEUE, main.cpp:43).  in holds the n
  * bodies of the whole system. */

@@ -133,6 +133,8 @@ PROTOTYPES = {
     "nb_wait": (C.c_int, [C.c_void_p]),
     "nb_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nb_sync_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nb_snapshot_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nb_snapshot_wait": (C.c_int, [C.c_void_p]),
     "nb_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "nb_host_unregister": (C.c_int, [C.c_void_p]),
     "nb_upload": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -104,6 +104,11 @@ struct nb_sim {
     bool own_acc = true;
     // the local items run on a side stream so that their tail and the head of the cross items share the chip
     // and the late items run there while the reduce-scatter is in flight
+    // pipelined snapshot (nb_snapshot_begin / _wait): D2H on its own stream, beside the steps that follow
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_copied = nullptr;
+    nb_body *snap_out = nullptr;
+    bool snap_direct = false, snap_pending = false;
     hipStream_t aux = nullptr;
     bool aux_local = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_late = nullptr;
@@ -357,6 +362,9 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
+    if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
+    if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
     if (s->staging) (void)hipHostFree(s->staging);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -492,6 +500,7 @@ extern "C" int nb_upload(nb_sim *s, const nb_body *in)
 {
     if (!s || !in) return nb_fail(NB_EINVAL, "nb_upload: NULL argument");
     if (bind(s)) return NB_EHIP;
+    if (nb_snapshot_wait(s)) return nb_last_error_code();      // the AoS staging array may still feed a pipelined snapshot
     return do_upload(s, in);
 }
 
@@ -1020,12 +1029,9 @@ extern "C" int nb_host_unregister(void *ptr)
     return NB_OK;
 }
 
-extern "C" int nb_sync(nb_sim *s, nb_body *out)
+// AoS view of the owned block into aos_dev, on the handle's stream
+static int launch_pack(nb_sim *s)
 {
-    if (!s || !out) return nb_fail(NB_EINVAL, "nb_sync: NULL argument");
-    if (bind(s)) return NB_EHIP;
-    const bool direct = is_pinned_host(out);
-    if (!direct && ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     if (s->dims3 && s->fp64)
         pack_bodies3<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double4 *)s->pos[s->cur], (const double4 *)s->vel, (const double4 *)s->acc,
@@ -1040,6 +1046,55 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
         pack_bodies<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float2 *)s->pos[s->cur], (const float *)s->mass,
                                                        (const float2 *)s->vel, (const float2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
     HIPCHK(hipGetLastError());
+    return NB_OK;
+}
+
+extern "C" int nb_snapshot_wait(nb_sim *s)
+{
+    if (!s) return nb_fail(NB_EINVAL, "nb_snapshot_wait: NULL handle");
+    if (!s->snap_pending) return NB_OK;
+    if (bind(s)) return NB_EHIP;
+    HIPCHK(hipEventSynchronize(s->ev_copied));
+    if (!s->snap_direct) memcpy(s->snap_out, s->staging, s->i_count * sizeof(nb_body));
+    s->snap_pending = false;
+    s->snap_out = nullptr;
+    return NB_OK;
+}
+
+extern "C" int nb_snapshot_begin(nb_sim *s, nb_body *out)
+{
+    if (!s || !out) return nb_fail(NB_EINVAL, "nb_snapshot_begin: NULL argument");
+    if (s->snap_pending) return nb_fail(NB_ESTATE, "nb_snapshot_begin: a snapshot is already in flight (call nb_snapshot_wait)");
+    if (s->in_step) return nb_fail(NB_ESTATE, "nb_snapshot_begin: a split step is in flight");
+    if (bind(s)) return NB_EHIP;
+    if (!s->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
+    }
+    s->snap_direct = is_pinned_host(out);
+    if (!s->snap_direct && ensure_staging(s)) return NB_EHIP;
+    // aos_dev is free again: the previous snapshot was waited for, and nb_sync / nb_upload synchronise before returning
+    int rc = launch_pack(s);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev_packed, s->stream));
+    HIPCHK(hipStreamWaitEvent(s->copy_stream, s->ev_packed, 0));
+    HIPCHK(hipMemcpyAsync(s->snap_direct ? (void *)out : s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->copy_stream));
+    HIPCHK(hipEventRecord(s->ev_copied, s->copy_stream));
+    s->snap_out = out;
+    s->snap_pending = true;
+    return NB_OK;
+}
+
+extern "C" int nb_sync(nb_sim *s, nb_body *out)
+{
+    if (!s || !out) return nb_fail(NB_EINVAL, "nb_sync: NULL argument");
+    if (bind(s)) return NB_EHIP;
+    int rc = nb_snapshot_wait(s);                     // aos_dev / staging may still be feeding a pipelined snapshot
+    if (rc) return rc;
+    const bool direct = is_pinned_host(out);
+    if (!direct && ensure_staging(s)) return NB_EHIP;
+    if ((rc = launch_pack(s))) return rc;
     HIPCHK(hipMemcpyAsync(direct ? (void *)out : s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (!direct) memcpy(out, s->staging, s->i_count * sizeof(nb_body));
@@ -1051,6 +1106,7 @@ extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
     if (!s || !out_xy) return nb_fail(NB_EINVAL, "nb_sync_positions: NULL argument");
     if (s->dims3) return nb_fail(NB_EINVAL, "nb_sync_positions: 2-D handles only (use nb_sync for dims = 3)");
     if (bind(s)) return NB_EHIP;
+    if (nb_snapshot_wait(s)) return nb_last_error_code();
     if (ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     if (s->fp64) {

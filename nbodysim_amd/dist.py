@@ -124,7 +124,8 @@ def ranks_agree(values: Sequence[int], group=None) -> Tuple[bool, list, list]:
     return lo == hi, lo, hi
 
 
-def agree_on_fastest(local_seconds: Dict[str, float], group=None, prefer: Sequence[str] = ("symmetric", "allgather")):
+def agree_on_fastest(local_seconds: Dict[str, float], group=None,
+                     prefer: Sequence[str] = ("symmetric", "symmetric+late", "symmetric-late", "allgather")):
     """Every rank passes its own timing of each candidate (``inf`` = candidate unavailable); the job's time of a
     candidate is the MAX over ranks (the slowest rank sets the step rate).  Returns (winner, {name: job seconds}),
     identical on every rank; ties and near-ties (within 1 %) go to the earlier name in ``prefer``."""
@@ -155,7 +156,10 @@ class DistributedSimulation:
     protocol   "auto"       the library's choice (symmetric where eligible)
                "symmetric"  the symmetric pair split; error if the system is not eligible
                "allgather"  north_star's protocol: one-sided kernels, one all-gather per step
-               "tune"       time ``tune_steps`` steps of each on a scratch copy, keep the faster (ranks agree)
+               "tune"       time ``tune_steps`` steps of each candidate on a scratch copy and keep the fastest (the ranks
+                            agree by all-reduce): the symmetric split as the library would size it, the same with the
+                            held-back "late" local items switched the other way (they hide the reduce-scatter; on by
+                            default from 8 ranks), and the all-gather protocol
     Extra keyword arguments go to ``Simulation`` (``sym_late_us``, ``sym_chunks_per_item`` ... the tuning fields of
     ``nb_params``; they must be the same on every rank and are verified to be).
     """
@@ -193,14 +197,15 @@ class DistributedSimulation:
         self._host_enqueue_s = 0.0
         self._host_steps = 0
 
+        extra: dict = {}
         if protocol == "tune" and world > 1:
-            protocol = self._tune(bodies, tune_steps, tune_dt)
+            protocol, extra = self._tune(bodies, tune_steps, tune_dt)
         elif protocol == "tune":
             protocol = "auto"
-        self._create(bodies, protocol)
+        self._create(bodies, protocol, extra)
 
     # -- construction ---------------------------------------------------------
-    def _create(self, bodies: np.ndarray, protocol: str) -> None:
+    def _create(self, bodies: np.ndarray, protocol: str, extra: Optional[dict] = None) -> None:
         """Allocate the replicas, create the handle, and verify that every rank got the same pair split.  A rank
         whose nb_create fails still reaches the collective, so the job fails on every rank instead of hanging."""
         from .simulation import Simulation
@@ -219,6 +224,7 @@ class DistributedSimulation:
                 self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
                 acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
             kw = dict(self._args)
+            kw.update(extra or {})
             if protocol == "allgather":
                 kw["symmetry"] = False
             self.sim = Simulation(
@@ -260,18 +266,26 @@ class DistributedSimulation:
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
 
-    def _tune(self, bodies: np.ndarray, steps: int, dt: float) -> str:
-        """Time `steps` steps of each protocol on a scratch copy of the system (2 untimed steps first), wall clock
+    def _tune(self, bodies: np.ndarray, steps: int, dt: float):
+        """Time `steps` steps of each candidate on a scratch copy of the system (2 untimed steps first), wall clock
         between barriers, MAX over ranks; the handles are destroyed again, so the simulation proper starts from
-        the caller's bodies at frame 0."""
+        the caller's bodies at frame 0.  Returns (protocol, extra Simulation keyword arguments)."""
         local: Dict[str, float] = {}
-        for cand in ("symmetric", "allgather"):
+        late_default_on = self.plan.world >= 8 and float(self._args.get("sym_late_us", 0.0)) == 0.0
+        flipped = ("symmetric-late", {"sym_late_us": -1.0}) if late_default_on else ("symmetric+late", {"sym_late_us": 40.0})
+        cands = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allgather": ("allgather", {})}
+        if float(self._args.get("sym_late_us", 0.0)) != 0.0:      # the caller fixed the late share: nothing to flip
+            del cands[flipped[0]]
+        for name, (cand, extra) in cands.items():
+            if local.get("symmetric") == float("inf") and cand == "symmetric":
+                local[name] = float("inf")
+                continue
             try:
-                self._create(bodies, cand)
+                self._create(bodies, cand, extra)
             except RuntimeError as e:
                 if "not eligible" not in str(e):
                     raise
-                local[cand] = float("inf")
+                local[name] = float("inf")
                 continue
             self.advance(2, dt)
             self.wait()
@@ -280,11 +294,11 @@ class DistributedSimulation:
             self.advance(steps, dt)
             self.wait()
             self.dist.barrier(group=self.group)
-            local[cand] = (time.perf_counter() - t0) / steps
+            local[name] = (time.perf_counter() - t0) / steps
             self.close()
         best, job = agree_on_fastest(local, self.group)
-        self.tuning = {"steps": steps, "ms_per_step": {k: v * 1e3 for k, v in job.items()}, "chosen": best}
-        return best
+        self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best}
+        return cands[best]
 
     # -- stepping ---------------------------------------------------------------
     @property

@@ -112,7 +112,13 @@ public:
         if (!sim_) throw std::runtime_error(std::string("nb_create: ") + nb_last_error());
         pin();
     }
-    ~Simulation() { unpin(); nb_destroy(sim_); }
+    ~Simulation()
+    {
+        if (snapshot_in_flight_) (void)nb_snapshot_wait(sim_);
+        unpin();
+        if (pinned_back_) (void)nb_host_unregister(pinned_back_);
+        nb_destroy(sim_);
+    }
     Simulation(const Simulation &) = delete;
     Simulation &operator=(const Simulation &) = delete;
 
@@ -122,10 +128,34 @@ public:
     void step()
     {
         check_size();
+        if (snapshot_in_flight_) { check(nb_snapshot_wait(sim_), "nb_snapshot_wait"); snapshot_in_flight_ = false; }
         if (bodies.data() != pinned_) pin();   // the vector's storage moved (same size): re-register it
         const float current_dt = SIMULATION_DT.load();
         check(nb_step(sim_, current_dt, 1), "nb_step");
         check(nb_sync(sim_, reinterpret_cast<nb_body *>(bodies.data())), "nb_sync");
+        ++frame;
+    }
+
+    // Pipelined form of step() for a viewer that can draw one frame late: advances one step and returns with `bodies`
+    // holding the state after the PREVIOUS call's step; the device-to-host copy of frame k (16.8 MB at N = 262 144)
+    // runs on a copy stream while the force of step k + 1 computes (nb_snapshot_begin / nb_snapshot_wait).
+    // The transfer lands in a second, page-locked vector that is swapped with `bodies` (O(1)) once it is complete,
+    // so the caller never reads a vector the copy engine is writing.  Call sync() to catch up to the current frame.
+    void step_overlapped()
+    {
+        check_size();
+        if (back_.size() != bodies.size()) {                   // first use: the second host buffer
+            back_ = bodies;
+            if (nb_host_register(back_.data(), back_.size() * sizeof(Body)) == NB_OK) pinned_back_ = back_.data();
+        }
+        check(nb_step(sim_, SIMULATION_DT.load(), 1), "nb_step");                                   // enqueue step k + 1
+        if (snapshot_in_flight_) {
+            check(nb_snapshot_wait(sim_), "nb_snapshot_wait");                                      // frame k has arrived in back_
+            bodies.swap(back_);
+            std::swap(pinned_, pinned_back_);
+        }
+        check(nb_snapshot_begin(sim_, reinterpret_cast<nb_body *>(back_.data())), "nb_snapshot_begin");   // frame k + 1 follows it
+        snapshot_in_flight_ = true;
         ++frame;
     }
 
@@ -135,7 +165,12 @@ public:
         check(nb_step(sim_, SIMULATION_DT.load(), k), "nb_step");
         frame += (size_t)k;
     }
-    void sync() { check_size(); check(nb_sync(sim_, reinterpret_cast<nb_body *>(bodies.data())), "nb_sync"); }
+    void sync()
+    {
+        check_size();
+        if (snapshot_in_flight_) { check(nb_snapshot_wait(sim_), "nb_snapshot_wait"); snapshot_in_flight_ = false; }
+        check(nb_sync(sim_, reinterpret_cast<nb_body *>(bodies.data())), "nb_sync");
+    }
     // After editing `bodies` in place on the host (same count).
     void upload() { check_size(); check(nb_upload(sim_, reinterpret_cast<const nb_body *>(bodies.data())), "nb_upload"); }
     nb_sim *handle() { return sim_; }
@@ -172,4 +207,7 @@ private:
     }
     nb_sim *sim_ = nullptr;
     Body *pinned_ = nullptr;
+    std::vector<Body> back_;            // step_overlapped(): the buffer the in-flight snapshot is written to
+    Body *pinned_back_ = nullptr;
+    bool snapshot_in_flight_ = false;
 };

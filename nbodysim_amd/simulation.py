@@ -126,6 +126,16 @@ class Simulation:
         L.check("nb_sync", self._lib.nb_sync(self._h, self.bodies.ctypes.data))
         return self.bodies
 
+    def snapshot_begin(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Pipelined ``sync``: start copying the state as of the work enqueued so far into ``out`` (default:
+        ``self.bodies``) and return at once; steps enqueued afterwards overlap the transfer.  Pair with ``snapshot_wait``."""
+        out = self.bodies if out is None else out
+        L.check("nb_snapshot_begin", self._lib.nb_snapshot_begin(self._h, out.ctypes.data))
+        return out
+
+    def snapshot_wait(self) -> None:
+        L.check("nb_snapshot_wait", self._lib.nb_snapshot_wait(self._h))
+
     def positions(self) -> np.ndarray:
         out = np.empty((self.i_count, 2), dtype=np.float32)
         L.check("nb_sync_positions", self._lib.nb_sync_positions(self._h, out.ctypes.data))

@@ -117,3 +117,71 @@ def test_cxx_default_constructed_simulation_is_the_reference_start():
     got = np.array([float(m.group(k)) for k in (3, 4, 5, 6)])
     want = np.concatenate([b["pos"][1], b["pos"][-1]]).astype(np.float64)
     assert np.allclose(got, want, rtol=1e-6, atol=0)
+
+
+def test_c_driver_restart_applies_the_dump_header(tmp_path):
+    """`nbody_main -load`: the run's parameters come from the dump header (eps, dt, rsqrt mode, sum order), so a
+    restart continues the SAME run: 8 steps in one go == 3 steps, dump, load, 5 steps — bit for bit in the
+    reference-arithmetic mode.  A forged body count in the header is refused before anything is allocated from it."""
+    exe = _host_program("nbody_main")
+    a, b, c = tmp_path / "a.nbd", tmp_path / "b.nbd", tmp_path / "c.nbd"
+    common = ["-n", "3000", "-eps", "0.07", "-dt", "0.002", "-quake", "-sequential"]
+
+    def run(*args):
+        r = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    run(*common, "-s", "6", "-dump", str(a))                     # 2 warm-up + 6 = frame 8
+    run(*common, "-s", "1", "-dump", str(b))                     # frame 3
+    out = run("-load", str(b), "-s", "3", "-dump", str(c))       # header supplies eps, dt, quake, sequential; 2 + 3 more steps
+    assert "eps 0.07, dt 0.002, fp32, quake, sequential" in out and "rsqrt=quake sum=sequential" in out
+    ba, _, pa = nb.read_bodies(a)
+    bc, _, pc = nb.read_bodies(c)
+    assert pc.rsqrt_mode == L.NB_RSQRT_QUAKE and pc.sum_order == L.NB_SUM_SEQUENTIAL and abs(pc.dt - 0.002) < 1e-9
+    for f in ("pos", "vel"):
+        assert np.array_equal(ba[f].view(np.uint32), bc[f].view(np.uint32)), f
+    raw = bytearray(b.read_bytes())
+    raw[16:24] = (1 << 58).to_bytes(8, "little")
+    bad = tmp_path / "bad.nbd"
+    bad.write_bytes(bytes(raw))
+    r = subprocess.run([str(exe), "-load", str(bad), "-s", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "out of range" in r.stderr
+
+
+def test_pipelined_snapshot_is_the_state_at_begin_and_overlaps_later_steps():
+    """nb_snapshot_begin / nb_snapshot_wait: the copy started after step k is frame k even though steps k+1, k+2 were
+    enqueued behind it; pageable and page-locked destinations; one snapshot in flight; nb_sync drains it."""
+    lib = nb.load()
+    ic = nb.plummer_2d(40000, 3)
+    with nb.Simulation(ic, eps=0.05) as sim:
+        sim.advance(2, 1e-3)
+        want = sim.sync().copy()                      # frame 2
+        for pinned in (False, True):
+            out = nb.bodies_array(40000)
+            if pinned:
+                L.check("nb_host_register", lib.nb_host_register(out.ctypes.data, out.nbytes))
+            try:
+                sim.upload(want)                       # back to frame 2's state (acc is carried in the records)
+                sim.snapshot_begin(out)
+                assert lib.nb_snapshot_begin(sim._h, out.ctypes.data) == L.NB_ESTATE        # one in flight
+                sim.advance(2, 1e-3)                   # runs while the copy is in flight
+                sim.snapshot_wait()
+                for f in ("pos", "vel", "mass", "radius"):
+                    assert np.array_equal(out[f].view(np.uint32), want[f].view(np.uint32)), (pinned, f)
+                later = sim.sync()
+                assert not np.array_equal(later["pos"], want["pos"])
+                sim.snapshot_wait()                    # nothing pending: no-op
+            finally:
+                if pinned:
+                    L.check("nb_host_unregister", lib.nb_host_unregister(out.ctypes.data))
+
+
+def test_cxx_adaptor_overlapped_step_delivers_the_same_frames_one_call_late():
+    """`Simulation::step_overlapped()` (double-buffered, pipelined D2H) against the reference's blocking pattern
+    `step(); SHARED_BODIES = simulation->bodies`: the same frame, bit for bit, after one more call."""
+    exe = _host_program("sim_thread_example")
+    r = subprocess.run([str(exe), "overlap", "65536", "12"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"blocking=([0-9.]+) ms/frame overlapped=([0-9.]+) ms/frame differing_bodies=(\d+)", r.stdout)
+    assert m and int(m.group(3)) == 0, r.stdout
