@@ -211,7 +211,8 @@ int nb_accelerations(nb_sim *s);
  * force (Quadtree.hpp:140-142): K = sum m v^2/2, U = -sum_{i<j} m_i m_j/sqrt(r^2+eps^2).
  * Replaces the unusable calculateMetrics (main.cpp:91-194) / Body::kinetic_energy
  * (Body.hpp:98-101).  On a sharded handle K and U are the owned block's share
- * (U_i counted as 1/2 sum_{j!=i}), so the shares of all ranks add up to the total. */
+ * (U of block B = - sum_{i in B} sum_{j > i} m_i m_j / sqrt(...): every unordered pair is
+ * counted by the handle that owns its lower index), so the shares of all ranks add up to the total. */
 int nb_energy(nb_sim *s, double *kinetic, double *potential);
 
 /* Counters: Simulation::frame (Simulation.hpp:53) and sizes. */

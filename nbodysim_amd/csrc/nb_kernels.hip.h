@@ -977,7 +977,9 @@ void pack_positions(float2 *__restrict__ out, const typename vec2_of<real>::type
 // ---------------------------------------------------------------------------
 // energy — fp64 accumulation whatever the state precision.
 //   ksum[b] = sum over the block's owned i of m v^2 / 2
-//   usum[b] = -1/2 sum_i m_i sum_{j != i} m_j / sqrt(r^2 + eps^2)
+//   usum[b] = - sum_i m_i sum_{j > i} m_j / sqrt(r^2 + eps^2)     (every unordered pair once: j-tiles below the
+//             block's first particle are skipped, so the sweep costs n^2/2 pair evaluations; the shares of the
+//             handles of a sharded run still add up to the total)
 // Per-block partials are summed on the host in block order (deterministic).
 // ---------------------------------------------------------------------------
 template <typename real>
@@ -996,7 +998,8 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
     const uint32_t gi = i_begin + (live ? li : i_count - 1);
     const double xi = (double)pos[gi].x, yi = (double)pos[gi].y;
     double u = 0.0;
-    for (uint32_t j0 = 0; j0 < n; j0 += TJ) {
+    const uint32_t first = ((i_begin + blockIdx.x * BLOCK) / TJ) * TJ;      // j-tile holding the block's first particle
+    for (uint32_t j0 = first; j0 < n; j0 += TJ) {
         const uint32_t j = j0 + t;
         __syncthreads();
         if (j < n) tile[t] = JD{(double)pos[j].x, (double)pos[j].y, (double)mass[j], 0.0};
@@ -1006,7 +1009,7 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
         for (uint32_t jj = 0; jj < cnt; ++jj) {
             const double dx = tile[jj].x - xi, dy = tile[jj].y - yi;
             const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
-            const double w = (j0 + jj == gi) ? 0.0 : tile[jj].m;
+            const double w = (j0 + jj > gi) ? tile[jj].m : 0.0;
             u = __builtin_fma(w, rsqrt_f64(r2), u);      // v_rsq_f64 + third-order step: 1.4e-16 relative
         }
     }
@@ -1015,7 +1018,7 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
         const double m = (double)mass[gi];
         const double vx = (double)vel[li].x, vy = (double)vel[li].y;
         k = 0.5 * m * (vx * vx + vy * vy);
-        uu = -0.5 * m * u;
+        uu = -m * u;
     }
     // wave64 reduction with shuffles, then across the 4 waves through LDS
 #pragma unroll

@@ -539,7 +539,7 @@ void pack_bodies3(BodyRec *__restrict__ aos, const typename vec4_of<real>::type 
     aos[li] = r;
 }
 
-// energy in fp64: K = sum m v^2 / 2, U = -1/2 sum_i m_i sum_{j != i} m_j / sqrt(r^2 + eps^2)
+// energy in fp64: K = sum m v^2 / 2, U = - sum_i m_i sum_{j > i} m_j / sqrt(r^2 + eps^2) (every unordered pair once)
 template <typename real>
 __global__ __launch_bounds__(BLOCK)
 void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, const typename vec4_of<real>::type *__restrict__ vel,
@@ -554,7 +554,8 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
     const auto pi = pos[gi];
     const double xi = pi.x, yi = pi.y, zi = pi.z;
     double u = 0.0;
-    for (uint32_t j0 = 0; j0 < n; j0 += TJ) {
+    const uint32_t first = ((i_begin + blockIdx.x * BLOCK) / TJ) * TJ;
+    for (uint32_t j0 = first; j0 < n; j0 += TJ) {
         const uint32_t j = j0 + t;
         __syncthreads();
         if (j < n) { const auto q = pos[j]; tile[t] = JD{(double)q.x, (double)q.y, (double)q.z, (double)q.w}; }
@@ -564,7 +565,7 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
         for (uint32_t jj = 0; jj < cnt; ++jj) {
             const double dx = tile[jj].x - xi, dy = tile[jj].y - yi, dz = tile[jj].z - zi;
             const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-            const double wgt = (j0 + jj == gi) ? 0.0 : tile[jj].m;
+            const double wgt = (j0 + jj > gi) ? tile[jj].m : 0.0;
             u = __builtin_fma(wgt, rsqrt_f64(r2), u);
         }
     }
@@ -573,7 +574,7 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
         const double m = (double)pi.w;
         const auto v = vel[li];
         k = 0.5 * m * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
-        uu = -0.5 * m * u;
+        uu = -m * u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { k += __shfl_down(k, off, 64); uu += __shfl_down(uu, off, 64); }
