@@ -633,7 +633,7 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
 // A sharded rank's late items are left out here (launch_sym_gather_late folds them in).
 static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
 {
-    const uint32_t n = (uint32_t)s->n, gg = (n + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
+    const uint32_t n = (uint32_t)s->n, per = s->dims3 ? (uint32_t)GATHER_T : (uint32_t)GATHER_P, gg = (n + per - 1) / per, tiles = s->sym_tiles;
     void *dst = s->sym_sharded ? s->acc_full : s->partial;
     const uint32_t *lo = s->sym_rowbase_dev, *hi = s->sym_rowbase_dev + tiles;      // [first row, first late row)
     const uint32_t *cb = s->sym_cov_begin_dev;                                      // coverage lists of the main gather
@@ -684,7 +684,7 @@ static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
 static int launch_sym_gather_late(nb_sim *s, double dt)
 {
     const uint32_t n = (uint32_t)s->n, ic = (uint32_t)s->i_count, ib = (uint32_t)s->i_begin;
-    const uint32_t gg = (ic + GATHER_P - 1) / GATHER_P, tiles = s->sym_tiles;
+    const uint32_t per = s->dims3 ? (uint32_t)GATHER_T : (uint32_t)GATHER_P, gg = (ic + per - 1) / per, tiles = s->sym_tiles;
     const uint32_t *lo = s->sym_rowbase_dev + tiles, *hi = s->sym_rowbase_dev + 2 * (size_t)tiles;   // [first late row, end row)
     const uint32_t *cb = s->sym_cov_begin_dev + (tiles + 1);                        // coverage lists of the late segments
     const SymCov *cov = s->sym_cov_dev + s->sym_cov_late_off;

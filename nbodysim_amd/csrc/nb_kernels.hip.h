@@ -522,18 +522,28 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 //            + sum over the coverage list of its tile (the travelling segments held here that meet the
 //              tile, in segment order) of the entries that cover k.
 //
-// 32 particles per workgroup, 8 threads per particle: thread (q, p) adds the rows r = q (mod 8)
-// of particle p's lists in ascending order, the 8 partials are then added in q order — a fixed
-// association whatever the launch, so results are reproducible run to run.
-constexpr int GATHER_Q = 8, GATHER_P = BLOCK / GATHER_Q;
+// 64 particles per workgroup, 8 threads per particle PAIR: thread (q, p) adds the rows r = q (mod 8) of the
+// lists of particles 2p and 2p + 1 in ascending order (one 16-byte load per row for the two float2 partials: the
+// gather is the one HBM-bound kernel of the step), the 8 partials are then added in q order — a fixed association
+// whatever the launch, so results are reproducible run to run.
+constexpr int GATHER_Q = 8, GATHER_T = BLOCK / GATHER_Q, GATHER_V = 2, GATHER_P = GATHER_T * GATHER_V;
 static_assert(SYM_SB % GATHER_P == 0, "the particles of a gather workgroup share a tile");
+
+// two adjacent elements (element index even: 16-byte aligned for float2)
+__device__ __forceinline__ void load_pair(const float2 *__restrict__ p, float2 &a, float2 &b)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    a = make_float2(v.x, v.y); b = make_float2(v.z, v.w);
+}
+__device__ __forceinline__ void load_pair(const double2 *__restrict__ p, double2 &a, double2 &b) { a = p[0]; b = p[1]; }
 
 // FUSE: the summed acceleration goes straight into kick_drift_one (whole-system handles: the owned
 // block is everything; sharded ranks: the LATE local items' slabs on top of the reduce-scattered sum
 // `base`), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum (sharded ranks:
 // the partial of every particle, to be reduce-scattered).
-// The launch covers particles [k0, k0 + kn); tile g's stationary rows are [row_lo[g], row_hi[g]), its
-// coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).
+// The launch covers particles [k0, k0 + kn), k0 a multiple of the tile size; tile g's stationary rows are
+// [row_lo[g], row_hi[g]), its coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).  Segment bounds are
+// multiples of 64 (or n) and segment offsets even (nb_plan.cpp), so a pair (k, k + 1), k even, is covered together.
 template <typename real, bool FUSE>
 __global__ __launch_bounds__(BLOCK)
 void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
@@ -551,33 +561,39 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 {
     typedef typename vec2_of<real>::type real2;
     __shared__ real2 part[GATHER_Q][GATHER_P];
-    const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
-    const uint32_t li = blockIdx.x * GATHER_P + p, k = k0 + li;
-    real2 a; a.x = 0; a.y = 0;
+    const uint32_t p = threadIdx.x % GATHER_T, q = threadIdx.x / GATHER_T;
+    const uint32_t li = blockIdx.x * GATHER_P + 2u * p, k = k0 + li;
+    real2 a0, a1; a0.x = a0.y = a1.x = a1.y = 0;
     if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
         const uint32_t r0 = row_lo[g], r1 = row_hi[g];
         for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
-            const real2 b = slab_s[(size_t)r * SYM_SB + loc];
-            a.x += b.x; a.y += b.y;
+            real2 b0, b1;
+            load_pair(slab_s + (size_t)r * SYM_SB + loc, b0, b1);        // rows are whole tiles: loc + 1 is inside
+            a0.x += b0.x; a0.y += b0.y; a1.x += b1.x; a1.y += b1.y;
         }
         const uint32_t c1 = cov_begin[g + 1];
         for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
             const SymCov cv = cov[i];
             if (k < cv.lo || k >= cv.hi) continue;
-            const real2 b = slab_r[cv.base + (int64_t)k];
-            a.x += b.x; a.y += b.y;
+            real2 b0, b1;
+            load_pair(slab_r + (cv.base + (int64_t)k), b0, b1);          // the element after an odd-length segment is padding
+            a0.x += b0.x; a0.y += b0.y;
+            if (k + 1 < cv.hi) { a1.x += b1.x; a1.y += b1.y; }
         }
     }
-    part[q][p] = a;
+    part[q][2u * p] = a0;
+    part[q][2u * p + 1] = a1;
     __syncthreads();
-    if (q == 0 && li < kn) {
-        real2 t = part[0][p];
+    // thread t < 64 finishes particle t of the workgroup
+    const uint32_t f = threadIdx.x, lf = blockIdx.x * GATHER_P + f;
+    if (f < (uint32_t)GATHER_P && lf < kn) {
+        real2 t = part[0][f];
 #pragma unroll
-        for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][p].x; t.y += part[j][p].y; }
-        if (base) { const real2 b = base[li]; t.x += b.x; t.y += b.y; }
-        if constexpr (FUSE) kick_drift_one<real, false>(t, li, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
-        else acc_sum[k] = t;
+        for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][f].x; t.y += part[j][f].y; }
+        if (base) { const real2 bb = base[lf]; t.x += bb.x; t.y += bb.y; }
+        if constexpr (FUSE) kick_drift_one<real, false>(t, lf, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
+        else acc_sum[k0 + lf] = t;
     }
 }
 

@@ -471,9 +471,9 @@ void sym_gather3(const typename vec4_of<real>::type *__restrict__ slab_s, const 
                  real dt_kick, real dt_drift, int flags)
 {
     typedef typename vec4_of<real>::type real4;
-    __shared__ real4 part[GATHER_Q][GATHER_P];
-    const uint32_t p = threadIdx.x % GATHER_P, q = threadIdx.x / GATHER_P;
-    const uint32_t li = blockIdx.x * GATHER_P + p, k = k0 + li;
+    __shared__ real4 part[GATHER_Q][GATHER_T];      // one particle per thread here: the elements are 16 / 32 bytes already
+    const uint32_t p = threadIdx.x % GATHER_T, q = threadIdx.x / GATHER_T;
+    const uint32_t li = blockIdx.x * GATHER_T + p, k = k0 + li;
     real4 a = make_real4<real>(0, 0, 0, 0);
     if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;

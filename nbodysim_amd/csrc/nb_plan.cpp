@@ -198,7 +198,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         const uint32_t lo = up((uint64_t)clo_ * SYM_CH, n), hi = up((uint64_t)chi_ * SYM_CH, n);
         pl.segs.push_back(SymSeg{I, lo, hi, group, off});
         base_of[I] = (int64_t)off - (int64_t)lo;
-        off += hi - lo;
+        off += (uint64_t)(hi - lo + 1u) & ~(uint64_t)1;   // even offsets: sym_gather loads two adjacent partials at once
     };
     for (uint32_t I = 0; I < tiles; ++I) {
         pl.rowbase[I] = row;

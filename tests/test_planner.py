@@ -37,10 +37,11 @@ def check_slab_ranges(items, info, n, esz=8):
     if len(lo) == 0:
         assert total == 0
         return
-    assert lo[0] == 0 and hi[-1] == total
-    assert (lo[1:] == hi[:-1]).all()
+    assert lo[0] == 0 and 0 <= total - hi[-1] <= 1
+    gaps = lo[1:] - hi[:-1]                 # back to back, but for the padding element after an odd-length (ragged) segment
+    assert ((gaps == 0) | (gaps == 1)).all()
     units = int(sym["cnt"].sum())
-    assert total <= units * CH and total > (units - len(set(sym["tile"]))) * CH      # = 64 per unit, ragged last chunk aside
+    assert total <= units * CH + len(lo) and total > (units - len(set(sym["tile"]))) * CH      # = 64 per unit, ragged last chunk aside
 
 
 @pytest.mark.parametrize("n,world", [(16384, 1), (20000, 1), (70001, 1), (262144, 1), (262144, 2), (262144, 4), (262144, 8),
