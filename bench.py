@@ -83,6 +83,55 @@ def host_cpu_info():
     return info
 
 
+class DeviceSampler:
+    """Clock and socket power of the busiest visible GPU during the timed region, read from the amdgpu hwmon files
+    (no privileges needed): the kernel is power-limited, so the step time of a given box follows
+    the clock it can hold under its 1.4 kW cap — this records it next to the number it explains."""
+
+    def __init__(self, period_s=0.02):
+        import glob
+        import threading
+        self.files = [(f, f.replace("power1_input", "freq1_input"), f.replace("power1_input", "power1_cap"))
+                      for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))]
+        self.period, self.samples, self._stop = period_s, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            best = None
+            for pw, fq, _ in self.files:
+                w = self._read(pw)
+                if w is not None and (best is None or w > best[0]):
+                    best = (w, self._read(fq))
+            if best:
+                self.samples.append(best)
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.files:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        pw = [s[0] * 1e-6 for s in self.samples]
+        fq = [s[1] * 1e-6 for s in self.samples if s[1]]
+        cap = max((self._read(c) or 0.0) for _, _, c in self.files) * 1e-6
+        return {"samples": len(pw), "power_w_mean": sum(pw) / len(pw), "power_w_max": max(pw), "power_cap_w": cap or None,
+                "sclk_mhz_mean": (sum(fq) / len(fq)) if fq else None, "sclk_mhz_min": min(fq) if fq else None,
+                "source": "amdgpu hwmon power1_input / freq1_input sampled every 20 ms during the timed region (rank 0's view)"}
+
+
 def cpu_baseline(ic, n, target_s=12.0):
     """Time the oracle on a bounded i-slice of the same N-body workload."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -200,12 +249,16 @@ def main() -> None:
             sim.profile_phases(True)
     barrier()
     torch.cuda.synchronize()
+    sampler = DeviceSampler() if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     advance(args.steps, DT)
     wait()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    device_state = sampler.stop() if sampler else None
     force_ms, launches = (0.0, 0)
     if not args.no_kernel_events:
         force_ms, launches = inner.profile_read()
@@ -346,6 +399,7 @@ def main() -> None:
                 "plan_hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
                 "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic) if traffic else None,
             },
+            "device_state": device_state,
             "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                        "steps": args.warmup + args.steps},
         }
