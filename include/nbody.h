@@ -252,7 +252,7 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *   NB_SHARD_ALLGATHER   (i_count < n): begin = local-tile force; host all-gathers the positions
  *                        into nb_pos_buffer(CURRENT) (may overlap begin); finish = remote force,
  *                        kick, drift.  One-sided kernels; one collective per step.
- *   NB_SHARD_SYMMETRIC   (shard_world > 1, tiled, eps > 0, large n, equal blocks of whole 2048-particle
+ *   NB_SHARD_SYMMETRIC   (shard_world > 1, tiled, eps >= 1e-12 (fp32) / > 0 (fp64), large n, equal blocks of whole 2048-particle
  *                        tiles): every rank evaluates 1/world of the UNORDERED pairs with the symmetric
  *                        kernel: begin = the pairs inside its own block (overlaps the all-gather still in
  *                        flight); host waits for the all-gather; nb_step_mid = its share of the cross-block

@@ -195,10 +195,15 @@ static void plan(nb_sim *s)
 // Symmetric path: tiled runs with eps > 0 that are big enough to fill the chip with (tile, chunk-range)
 // items — either the whole system on one GPU, or (shard_world > 1) this rank's share of the pairs of a
 // sharded run.  NB_FLAG_NO_SYMMETRY forces the one-sided kernels.
+// The branch-free pair body lets a particle meet itself (and coincident particles meet): r = 0 gives
+// 0 x (eps^2)^(-3/2), which is exactly 0 only while (1/eps)^3 is finite — in fp32 down to eps ~ 1.5e-13.
+// Below that (and for eps = 0) the one-sided kernels keep the reference's `if (r_sq > 0)` guard (Quadtree.hpp:139).
+static bool needs_guard(const nb_sim *s) { return s->fp64 ? !(s->p.eps > 0.0f) : !(s->p.eps >= 1e-12f); }
+
 static bool sym_eligible(const nb_sim *s)
 {
     if (s->p.flags & NB_FLAG_NO_SYMMETRY) return false;
-    if (s->p.sum_order != NB_SUM_TILED || !(s->p.eps > 0.0f)) return false;
+    if (s->p.sum_order != NB_SUM_TILED || needs_guard(s)) return false;
     if (s->fp64 && s->p.rsqrt_mode != NB_RSQRT_EXACT) return false;
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
     if (s->n < 8 * (size_t)SYM_SB) return false;
@@ -727,7 +732,7 @@ static int launch_force(nb_sim *s, const ForceJob &j)
     if (s->sym && &j == &s->job_all) return launch_force_sym(s);
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
-    const bool guard = s->p.eps == 0.0f;
+    const bool guard = needs_guard(s);
     const uint32_t ic = (uint32_t)s->i_count;
     if (s->dims3 && s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;

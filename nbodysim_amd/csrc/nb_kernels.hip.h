@@ -265,12 +265,14 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                 const v2f dy = yj - yi[p];
                 v2f r2, inv;
                 if constexpr (GUARD) {
-                    // eps == 0: keep the reference's `if (r_sq > 0)` (Quadtree.hpp:139)
+                    // eps == 0 or too small for 1/r^3 of a coincident pair to stay finite: keep the reference's
+                    // `if (r_sq > 0)` around `fast_inv_sqrt(r_sq + e_sq)` (Quadtree.hpp:139-140)
                     r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+                    const v2f t2 = r2 + e2;
                     if constexpr (RSQ == RSQ_EXACT)
-                        inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                        inv = (v2f){__builtin_amdgcn_rsqf(t2.x), __builtin_amdgcn_rsqf(t2.y)};
                     else
-                        inv = quake_rsqrt2(r2);
+                        inv = quake_rsqrt2(t2);
                     inv.x = r2.x > 0.f ? inv.x : 0.f;
                     inv.y = r2.y > 0.f ? inv.y : 0.f;
                 } else {

@@ -133,8 +133,9 @@ void force_tiled3_f32(const float4 *__restrict__ pos, float4 *__restrict__ parti
                 v2f r2, inv;
                 if constexpr (GUARD) {
                     r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-                    else inv = quake_rsqrt2(r2);
+                    const v2f t2 = r2 + e2;
+                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(t2.x), __builtin_amdgcn_rsqf(t2.y)};
+                    else inv = quake_rsqrt2(t2);
                     inv.x = r2.x > 0.f ? inv.x : 0.f;
                     inv.y = r2.y > 0.f ? inv.y : 0.f;
                 } else {

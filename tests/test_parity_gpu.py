@@ -163,6 +163,35 @@ def test_tiled_eps0_guard(nbo, rsqrt):
     assert np.max(np.abs(acc - a64)) < 1e-5 * np.max(np.abs(a64))
 
 
+@pytest.mark.parametrize("n,dims", [(900, 2), (20000, 2), (20000, 3)])
+@pytest.mark.parametrize("eps", [1e-20, 1e-13])
+def test_tiny_softening_with_coincident_bodies_stays_finite(nbo, n, dims, eps):
+    """A softening too small for (1/eps)^3 to be finite in fp32 (the branch-free pair body would produce
+    0 x inf = NaN for a body meeting itself or a coincident one) selects the guarded one-sided kernel — the
+    reference's `if (r_sq > 0)` around `fast_inv_sqrt(r_sq + e_sq)`, Quadtree.hpp:139-140 — also where the
+    symmetric kernel would otherwise run (n = 20 000); fp64 handles keep the symmetric kernel."""
+    b = random_bodies(n, seed=5) if dims == 2 else nb.plummer_3d(n, 5)
+    if dims == 3:
+        b = b.view(nb.BODY3_DTYPE)
+    b["pos"][1] = b["pos"][2]
+    with nb.Simulation(b, eps=eps, dims=dims) as sim:
+        assert "symmetric=0" in sim.describe()
+        acc = sim.accelerations().astype(np.float64)
+    assert np.isfinite(acc).all()
+    if dims == 2:
+        ax, ay = nbo.accel_f64(nbo.state_from_bodies(b, np.float64), float(np.float32(eps)))
+        a64 = np.stack([ax, ay], 1)
+    else:
+        st = nbo.state3_from_bodies(b)
+        a64 = np.stack(nbo.accel3_f64(st, float(np.float32(eps))), 1)
+    assert np.max(np.abs(acc - a64)) < 1e-5 * np.max(np.abs(a64))
+    if n >= 16384 and dims == 2:
+        with nb.Simulation(b, eps=eps, precision="fp64") as sim:
+            assert "symmetric=1" in sim.describe()
+            a = sim.accelerations().astype(np.float64)
+        assert np.isfinite(a).all() and np.max(np.abs(a - a64)) < 1e-6 * np.max(np.abs(a64))
+
+
 @pytest.mark.parametrize("js", [1, 2, 3, 4, 8, 11, 16, 32])
 def test_j_slices_and_lane_blocking_agree(nbo, js):
     ic = nb.plummer_2d(8192, 9)
