@@ -434,6 +434,19 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
+    if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 ||
+        (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {
+        nb_set_error("nb_create: tuning field out of range (sym_chunks_per_item >= 0, sym_aux_stream in -1..1, lanes_p in {0,1,2,4}, j_slices >= 0)");
+        return nullptr;
+    }
+    if (p.sym_tail[0] != 0.0f || p.sym_tail[1] != 0.0f || p.sym_tail[2] != 0.0f) {
+        if (!(p.sym_tail[0] > 0.0f && p.sym_tail[0] <= p.sym_tail[1] && p.sym_tail[1] <= p.sym_tail[2] && p.sym_tail[2] <= 1.0f)) {
+            nb_set_error("nb_create: sym_tail must be 0 < a <= b <= c <= 1 (or all 0 for the defaults)");
+            return nullptr;
+        }
+    }
     if (p.dims == 0) p.dims = 2;
     if (p.dims != 2 && p.dims != 3) { nb_set_error("nb_create: dims must be 2 or 3"); return nullptr; }
     if (p.dims == 3 && (p.sum_order != NB_SUM_TILED || p.extras != 0)) {

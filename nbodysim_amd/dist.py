@@ -404,6 +404,12 @@ class DistributedSimulation:
             k, u = float(t[0]), float(t[1])
         return k, u
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def close(self) -> None:
         if self.sim is not None:
             self.wait()
