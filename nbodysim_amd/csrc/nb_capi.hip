@@ -476,6 +476,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
 
     auto fail = [&](const char *what, hipError_t e) -> nb_sim * {
         free_all(s);
+        (void)hipGetLastError();        // do not leave the failure sticky for the next handle's launch checks
         nb_fail(hip_code(e), "nb_create: %s: %s", what, hipGetErrorString(e));
         return nullptr;
     };
@@ -507,8 +508,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->ered_blocks = (s->i_count + BLOCK - 1) / BLOCK;
     if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
 
-    if ((s->sym || s->sym_sharded) && plan_sym(s) != NB_OK) { free_all(s); return nullptr; }
-    if (do_upload(s, init) != NB_OK) { free_all(s); return nullptr; }
+    if ((s->sym || s->sym_sharded) && plan_sym(s) != NB_OK) { free_all(s); (void)hipGetLastError(); return nullptr; }
+    if (do_upload(s, init) != NB_OK) { free_all(s); (void)hipGetLastError(); return nullptr; }
     return s;
 }
 

@@ -678,6 +678,14 @@ def test_symmetric_path_memory_cap_falls_back_to_the_one_sided_kernel():
     ic = nb.plummer_2d(n, 3)
     with nb.Simulation(ic, eps=0.01) as sim:
         assert "symmetric=0" in sim.describe() and sim.sym_info()["enabled"] == 0
+    # an allocation that cannot fit (32 768 j-slices x 8.4 M particles x 8 B = 2.2 TB of partial sums) fails nb_create
+    # with NB_ENOMEM — the code survives the NULL handle — and leaves nothing sticky behind for the next handle
+    with pytest.raises(nb.NBodyError) as e:
+        nb.Simulation(ic, eps=0.01, symmetry=False, j_slices=32768)
+    assert e.value.code == L.NB_ENOMEM, e.value
+    with nb.Simulation(nb.plummer_2d(4096, 1), eps=0.05) as sim:
+        sim.advance(2, 1e-3)
+        assert np.isfinite(sim.sync()["pos"]).all()
 
 
 def test_two_million_bodies_symmetric_kernel_properties():
