@@ -132,13 +132,21 @@ class DeviceSampler:
                 "source": "amdgpu hwmon power1_input / freq1_input sampled every 20 ms during the timed region (rank 0's view)"}
 
 
-def cpu_baseline(ic, n, target_s=12.0):
-    """Time the oracle on a bounded i-slice of the same N-body workload."""
+def cpu_baseline(ic, n, target_s=10.0):
+    """The CPU figures beside the GPU number, on a bounded i-slice of the same workload (all n j-particles):
+    * kind "reference" — the compiled reference's OWN pairwise loop (Quadtree::acc, Quadtree.hpp:113-155, driven as a
+      direct sum through a single-leaf tree and fanned over std::async tasks like Simulation::attract) from
+      oracle/_ref/libnbref.so, when that prebuilt checker travelled here;
+    * "port" — the C restatement of that loop (bit-identical results; SoA, OpenMP, vectorised across i), always.
+    The main object is the reference when available, with the port beside it; otherwise the port."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import nbo  # checker / baseline only
 
     st = nbo.state_from_bodies(ic)
     threads = nbo.set_threads(0)
+    host = host_cpu_info()
+    where = (f"OpenMP {threads} threads (nproc {host['nproc']}, affinity {host['affinity']}, cgroup quota {host['cgroup_cpus']} CPUs) "
+             f"on {host['model']}")
     calib = min(n, 64 * threads)                 # a few i-blocks per thread
     t0 = time.perf_counter()
     nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, calib)
@@ -146,18 +154,40 @@ def cpu_baseline(ic, n, target_s=12.0):
     rate = calib * n / max(t_cal, 1e-6)
     islice = int(min(n, max(calib, (rate * target_s / n) // (16 * threads) * (16 * threads))))
     t0 = time.perf_counter()
-    nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, islice)
+    ax, ay = nbo.accel_f32(st, EPS, nbo.RSQRT_QUAKE, 0, islice)
     t = time.perf_counter() - t0
-    host = host_cpu_info()
-    return {
+    port = {
         "value": islice * n / t,
         "unit": "pair interactions/s",
         "cores": threads,
         "kind": "port",
         "host": host,
         "sample": f"reference pairwise arithmetic (Quake rsqrt, fp32, sequential j) for the first {islice} of {n} "
-                  f"i-particles against all {n} j = {islice * n:.3e} pairs in {t:.2f} s; OpenMP {threads} threads "
-                  f"(nproc {host['nproc']}, affinity {host['affinity']}, cgroup quota {host['cgroup_cpus']} CPUs) on {host['model']}",
+                  f"i-particles against all {n} j = {islice * n:.3e} pairs in {t:.2f} s; {where}",
+    }
+    try:
+        if not nbo.have_ref() or not hasattr(nbo.ref(), "ref_direct_acc_timed"):
+            return port
+        flat = nbo.state_to_flat(st).astype(np.float32)
+        secs, _ = nbo.ref_direct_acc_timed(flat, EPS, 0, 16 * threads, threads)
+        rrate = 16 * threads * n / max(secs, 1e-6)
+        rslice = int(min(n, max(16 * threads, (rrate * target_s / n) // threads * threads)))
+        secs, out = nbo.ref_direct_acc_timed(flat, EPS, 0, rslice, threads)
+        k = min(rslice, islice)
+        same = bool(np.array_equal(out[:k, 4], ax[:k]) and np.array_equal(out[:k, 5], ay[:k]))
+    except (OSError, RuntimeError, AttributeError):
+        return port
+    return {
+        "value": rslice * n / secs,
+        "unit": "pair interactions/s",
+        "cores": threads,
+        "kind": "reference",
+        "host": host,
+        "sample": f"the compiled reference's own Quadtree::acc leaf loop (64-byte AoS bodies, Quake rsqrt, fp32) for the first {rslice} of {n} "
+                  f"i-particles against all {n} j = {rslice * n:.3e} pairs in {secs:.2f} s, {threads} std::async tasks on contiguous i-chunks as in "
+                  f"Simulation::attract; " + where.replace("OpenMP ", "", 1),
+        "bitwise_equal_to_port": same,
+        "port": {k2: port[k2] for k2 in ("value", "unit", "cores", "sample")},
     }
 
 
@@ -410,6 +440,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline and args.dims == 2:
             line["cpu_baseline"] = cpu_baseline(ic, n)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            if "port" in line["cpu_baseline"]:
+                line["cpu_baseline"]["port"]["gpu_over_cpu"] = value / line["cpu_baseline"]["port"]["value"]
             # context only: the reference's PRODUCTION path is Barnes-Hut, not O(N^2)
             line["cpu_baseline"]["context"] = ("reference Simulation::step() (Barnes-Hut theta=1 + collide) ran at 2.31 steps/s at "
                                                "N=262144 in the survey container (8 vCPU Xeon), not on this box; never mixed into pair interactions/s")

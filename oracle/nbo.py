@@ -251,6 +251,9 @@ def ref() -> C.CDLL:
         l.ref_fast_inv_sqrt.argtypes = [_f32p, _f32p, C.c_size_t]
         l.ref_direct_acc.argtypes = [_f32p, C.c_size_t, C.c_float]
         l.ref_direct_step.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int]
+        if hasattr(l, "ref_direct_acc_timed"):
+            l.ref_direct_acc_timed.restype = C.c_double
+            l.ref_direct_acc_timed.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_size_t, C.c_size_t, C.c_int]
         l.ref_step.restype = C.c_size_t
         l.ref_step.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float, C.c_int]
         l.ref_default_ics.restype = C.c_size_t
@@ -264,3 +267,11 @@ def ref_layout() -> dict:
     ref().ref_layout(out)
     keys = ["sizeof_Body", "alignof_Body", "off_pos", "off_vel", "off_acc", "off_mass", "off_radius", "sizeof_Vec2"]
     return {k: int(v) for k, v in zip(keys, out)}
+
+
+def ref_direct_acc_timed(flat: np.ndarray, eps: float, i_begin: int, i_end: int, threads: int):
+    """Seconds the compiled reference's own pairwise loop takes for i in [i_begin, i_end) against all bodies
+    (std::async fan-out like Simulation::attract); also returns the flat records with acc filled for that slice."""
+    out = np.ascontiguousarray(flat, dtype=np.float32).copy()
+    secs = ref().ref_direct_acc_timed(out.reshape(-1), out.shape[0], float(eps), int(i_begin), int(i_end), int(threads))
+    return float(secs), out

@@ -22,8 +22,10 @@
 // in this container.  It does not exist on the GPU box unless the prebuilt .so
 // travelled there.
 #include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstring>
+#include <future>
 #include <vector>
 
 #include "Simulation.hpp"  // pulls Body.hpp, Quadtree.hpp, Vec2.hpp (+ raylib.h for Vector2)
@@ -113,6 +115,35 @@ void ref_direct_acc(float *flat, size_t n, float eps)
     Quadtree q(1.0f, eps, 16);
     direct_acc(q, b);
     to_flat(b, flat);
+}
+
+// Wall time (seconds) of the reference's own pairwise loop — Quadtree::acc through the single-leaf tree — for the
+// i-particles [i_begin, i_end) against all n bodies, fanned over `threads` std::async tasks on contiguous i-chunks,
+// the way Simulation::attract() fans its i-loop (Simulation.hpp:180-208).  This is the "reference's own CPU loop"
+// figure of bench.py's cpu_baseline (kind "reference"); the accelerations are written back for a cross-check.
+double ref_direct_acc_timed(float *flat, size_t n, float eps, size_t i_begin, size_t i_end, int threads)
+{
+    std::vector<Body> b = from_flat(flat, n);
+    Quadtree q(1.0f, eps, 16);
+    make_single_leaf(q, b);
+    if (i_end > n) i_end = n;
+    if (i_begin >= i_end) return 0.0;
+    if (threads < 1) threads = 1;
+    const size_t count = i_end - i_begin, chunk = (count + (size_t)threads - 1) / (size_t)threads;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::future<void>> tasks;
+    for (size_t start = i_begin; start < i_end; start += chunk)
+    {
+        const size_t stop = start + chunk < i_end ? start + chunk : i_end;
+        tasks.push_back(std::async(std::launch::async, [&q, &b, start, stop]() {
+            for (size_t i = start; i < stop; ++i)
+                b[i].acc = q.acc(b[i].pos, b);
+        }));
+    }
+    for (auto &t : tasks) t.get();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    to_flat(b, flat);
+    return secs;
 }
 
 // REF-DIRECT nsteps of kick-drift.  use_body_update=1 integrates through the
