@@ -204,7 +204,7 @@ def main() -> None:
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses the multi-rank path on a one-GPU box")
-    ap.add_argument("--protocol", default="tune", choices=["tune", "auto", "symmetric", "allgather"],
+    ap.add_argument("--protocol", default="tune", choices=["tune", "auto", "symmetric", "allreduce", "allgather"],
                     help="multi-GPU exchange: tune (default) times a few steps of the symmetric pair split (reduce-scatter + "
                          "all-gather) and of north_star's all-gather protocol before the timed region and keeps the faster; "
                          "the others force one")
@@ -331,7 +331,7 @@ def main() -> None:
         um = "uniform_mass=1" in inner.describe()
         kernel = ("force_sym" if symmetric else "force_tiled") + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64")
         # force launches per step on this rank: 1 (single GPU) or up to 3 (local + cross + late / local + remote ranges)
-        pairs_this_rank = float(inner.i_count) * float(n) * args.steps
+        pairs_this_rank = float(n // world) * float(n) * args.steps      # 1/world of the ordered pairs, whatever the protocol
         if launches and force_ms > 0 and world == 1:
             kern_s = force_ms * 1e-3
             avg_launch_ms = force_ms / launches
@@ -372,8 +372,9 @@ def main() -> None:
                            f"registers, travelling chunk rotated through the lanes)" if symmetric else "one-sided, j-particles through LDS tiles of 256"))
         else:
             workload = (f"N={n} {args.precision} direct O(N^2) sharded over {world} MI355X, "
-                        + ("symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step"
-                           if sim.symmetric else "all-gather of (x,y) per step overlapped with the local-tile force"))
+                        + {"symmetric": "symmetric pair split: reduce-scatter of accelerations + all-gather of (x,y) per step",
+                           "allreduce": "symmetric pair split, replicated integration: one all-reduce of the accelerations per step",
+                           "allgather": "all-gather of (x,y) per step overlapped with the local-tile force"}[sim.protocol])
         line = {
             "metric": f"particle-pair interactions/sec at N={n:,} (direct O(N^2) softened gravity + kick/drift step)",
             "value": value,

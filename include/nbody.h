@@ -102,7 +102,8 @@ enum { NB_INTEGRATOR_KICK_DRIFT = 0, /* Simulation.hpp:129-131,160-163 (referenc
 enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered pair evaluated); a sharded
                                          handle then uses the NB_SHARD_ALLGATHER protocol */
        NB_FLAG_NO_UNIFORM_MASS = 2,   /* keep the per-pair mass multiply even when all masses are equal */
-       NB_FLAG_NO_GUIDED_TAIL  = 4 }; /* symmetric planner: uniform work items (no finer items at the end) */
+       NB_FLAG_NO_GUIDED_TAIL  = 4,   /* symmetric planner: uniform work items (no finer items at the end) */
+       NB_FLAG_SHARD_ALLREDUCE = 8 }; /* with shard_world > 1 and i_count = n: the NB_SHARD_ALLREDUCE protocol below */
 
 /* ---- parameters ----------------------------------------------------------- */
 typedef struct nb_params {
@@ -261,8 +262,15 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *                        block; host starts the all-gather of the new positions.  (From 8 ranks on,
  *                        nb_step_mid also starts a held-back share of the own-block pairs on a side stream;
  *                        it runs while the reduce-scatter is in flight and nb_step_finish adds its result to
- *                        nb_acc_buffer(1) — nothing changes for the host.) */
-enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2 };
+ *                        nb_acc_buffer(1) — nothing changes for the host.)
+ *   NB_SHARD_ALLREDUCE   (NB_FLAG_SHARD_ALLREDUCE, shard_world > 1, i_begin = 0, i_count = n, otherwise as
+ *                        NB_SHARD_SYMMETRIC; 2-D): every rank evaluates its 1/world of the unordered pairs and then
+ *                        integrates ALL n particles itself: begin = all its items, then its partial acceleration of
+ *                        every particle into nb_acc_buffer(0); the host ALL-REDUCES that buffer in place (sum; every
+ *                        rank must receive the same bits, which ring / tree all-reduces deliver); finish = kick, drift of
+ *                        all n.  One collective per step, no position exchange; every rank holds the whole state
+ *                        (nb_sync returns all n bodies, nb_energy the total). */
+enum { NB_SHARD_NONE = 0, NB_SHARD_ALLGATHER = 1, NB_SHARD_SYMMETRIC = 2, NB_SHARD_ALLREDUCE = 3 };
 int   nb_shard_protocol(const nb_sim *s);
 /* Exchange for a host that drives SEVERAL sharded handles from one process (e.g. one per GPU of
  * the node, no RCCL): every handle's owned block of its CURRENT replica is copied into the CURRENT
@@ -274,6 +282,9 @@ int   nb_exchange_positions(nb_sim *const *sims, int count);
  * reduce-scatter — every handle's nb_acc_buffer(1) receives the sum, in rank order, of all handles'
  * partial accelerations of its block.  Call it between nb_step_mid and nb_step_finish. */
 int   nb_exchange_accelerations(nb_sim *const *sims, int count);
+/* Same host, NB_SHARD_ALLREDUCE handles: the in-process all-reduce — every handle's nb_acc_buffer(0) receives the sum,
+ * in rank order, of all handles' partial accelerations.  Call it between nb_step_begin and nb_step_finish. */
+int   nb_exchange_allreduce(nb_sim *const *sims, int count);
 void *nb_acc_buffer(nb_sim *s, int which);   /* 0: full-n partial, 1: owned block sum (NULL if unused) */
 int   nb_step_begin(nb_sim *s, float dt);
 int   nb_step_mid(nb_sim *s);      /* NB_SHARD_SYMMETRIC only (no-op otherwise): see below */

@@ -27,8 +27,8 @@ NB_SUM_TILED, NB_SUM_SEQUENTIAL = 0, 1
 NB_EXTRA_VCLAMP, NB_EXTRA_BOUNDARY = 1, 2
 NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
-NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC = 0, 1, 2
-NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL = 1, 2, 4
+NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1, 2, 3
+NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE = 1, 2, 4, 8
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(
@@ -156,6 +156,7 @@ PROTOTYPES = {
     "nb_shard_protocol": (C.c_int, [C.c_void_p]),
     "nb_exchange_positions": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_exchange_accelerations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "nb_exchange_allreduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_acc_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),

@@ -100,6 +100,10 @@ struct nb_sim {
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
+    // symmetric REPLICATED protocol (NB_FLAG_SHARD_ALLREDUCE): the handle holds this rank's share of the pairs like a
+    // sharded one, but integrates ALL n particles itself after the host has all-reduced the partial accelerations:
+    // one collective per step, every rank keeps the whole (bit-identical) state
+    bool sym_replicated = false;
     void *acc_full = nullptr, *acc_owned = nullptr;     // reduce-scatter input (n) / output (i_count), (ax,ay) reals
     bool own_acc = true;
     // the local items run on a side stream so that their tail and the head of the cross items share the chip
@@ -229,6 +233,13 @@ static bool want_sym(const nb_sim *s)          // single handle owns everything
     return s->i_count == s->n && s->p.shard_world <= 1 && sym_eligible(s);
 }
 
+static bool want_sym_replicated(const nb_sim *s)  // rank of a run that all-reduces accelerations and integrates everything everywhere
+{
+    const size_t w = (size_t)s->p.shard_world;
+    return (s->p.flags & NB_FLAG_SHARD_ALLREDUCE) && s->p.shard_world > 1 && s->i_count == s->n && !s->dims3 &&
+           s->p.integrator == NB_INTEGRATOR_KICK_DRIFT && sym_eligible(s) && s->n / w >= 2 * (size_t)SYM_SB && s->n % (w * SYM_SB) == 0;
+}
+
 static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
 {
     const size_t w = (size_t)s->p.shard_world;
@@ -304,10 +315,11 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
 static int plan_sym(nb_sim *s)
 {
     const uint32_t n = (uint32_t)s->n;
-    const uint32_t world = s->sym_sharded ? (uint32_t)s->p.shard_world : 1u;
-    const uint32_t rank = s->sym_sharded ? (uint32_t)s->p.shard_rank : 0u;
+    const bool split = s->sym_sharded || s->sym_replicated;
+    const uint32_t world = split ? (uint32_t)s->p.shard_world : 1u;
+    const uint32_t rank = split ? (uint32_t)s->p.shard_rank : 0u;
     SymPlan pl;
-    build_sym_plan(n, (uint32_t)s->cus, rank, world, tuning_of(s->p, s->fp64, s->cus, world, s->sym_sharded), pl);
+    build_sym_plan(n, (uint32_t)s->cus, rank, world, tuning_of(s->p, s->fp64, s->cus, world, s->sym_sharded), pl);   // late items: sharded only
     const uint32_t tiles = pl.tiles, row = pl.rowbase[tiles];
     s->sym_info.struct_size = (uint32_t)sizeof(nb_sym_info);
     fill_sym_info(pl, n, world, s->cus, s->esz, true, &s->sym_info);
@@ -343,11 +355,11 @@ static int plan_sym(nb_sim *s)
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_late, hipEventDisableTiming));
     }
-    if (s->sym_sharded) {
+    if (split) {
         if (s->p.acc_buffers[0]) { s->acc_full = s->p.acc_buffers[0]; s->acc_owned = s->p.acc_buffers[1]; s->own_acc = false; }
         else {
             HIPCHK(hipMalloc(&s->acc_full, (size_t)n * s->esz));
-            HIPCHK(hipMalloc(&s->acc_owned, s->i_count * s->esz));
+            if (s->sym_sharded) HIPCHK(hipMalloc(&s->acc_owned, s->i_count * s->esz));
         }
     }
     return NB_OK;
@@ -434,7 +446,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 ||
         (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {
@@ -491,6 +503,8 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     // decided once (eligibility looks at the free device memory, which the allocations below change)
     s->sym = want_sym(s);
     s->sym_sharded = want_sym_sharded(s);
+    s->sym_replicated = want_sym_replicated(s);
+    if (s->sym_replicated) s->sym = false;          // the whole-system plan is not built: this rank evaluates its share only
     plan(s);
     const size_t r2 = s->esz;
     if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; }
@@ -508,7 +522,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     s->ered_blocks = (s->i_count + BLOCK - 1) / BLOCK;
     if ((e = hipMalloc((void **)&s->ered_dev, 2 * s->ered_blocks * sizeof(double))) != hipSuccess) return fail("hipMalloc energy", e);
 
-    if ((s->sym || s->sym_sharded) && plan_sym(s) != NB_OK) { free_all(s); (void)hipGetLastError(); return nullptr; }
+    if ((s->sym || s->sym_sharded || s->sym_replicated) && plan_sym(s) != NB_OK) { free_all(s); (void)hipGetLastError(); return nullptr; }
     if (do_upload(s, init) != NB_OK) { free_all(s); (void)hipGetLastError(); return nullptr; }
     return s;
 }
@@ -653,7 +667,7 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
 static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
 {
     const uint32_t n = (uint32_t)s->n, per = s->dims3 ? (uint32_t)GATHER_T : (uint32_t)GATHER_P, gg = (n + per - 1) / per, tiles = s->sym_tiles;
-    void *dst = s->sym_sharded ? s->acc_full : s->partial;
+    void *dst = (s->sym_sharded || s->sym_replicated) ? s->acc_full : s->partial;
     const uint32_t *lo = s->sym_rowbase_dev, *hi = s->sym_rowbase_dev + tiles;      // [first row, first late row)
     const uint32_t *cb = s->sym_cov_begin_dev;                                      // coverage lists of the main gather
     const int nxt = s->cur ^ 1, kd = INTEG_KICK | INTEG_DRIFT;
@@ -859,6 +873,13 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     s->in_step = true;
+    if (s->sym_replicated) {
+        // every position is already here (each rank integrates everything): all items in one launch, then this rank's
+        // PARTIAL acceleration of every particle -> acc_full, which the host all-reduces before nb_step_finish
+        int rc = launch_sym_items(s, 0, s->sym_items);
+        if (rc) return rc;
+        return launch_sym_gather(s, false, 0.0);
+    }
     if (s->sym_sharded) {
         // pairs inside my own block: no remote data needed.  On the side stream (ordered after everything
         // enqueued so far), so the cross items of nb_step_mid fill the CUs its last workgroups leave idle.
@@ -905,6 +926,25 @@ extern "C" int nb_step_finish(nb_sim *s)
     s->in_step = false;
     int rc;
     uint32_t nslabs;
+    if (s->sym_replicated) {
+        // acc_full holds the all-reduced acceleration of every particle: kick and drift them all
+        const uint32_t nn = (uint32_t)s->n, g = (nn + BLOCK - 1) / BLOCK;
+        const int nxt = s->cur ^ 1;
+        const float dt = s->pending_dt;
+        if (s->fp64)
+            integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
+                                                                 (double2 *)s->acc, (const double2 *)s->acc_full, 1u, 0u, nn,
+                                                                 (double)dt, (double)dt, s->p.extras, INTEG_KICK | INTEG_DRIFT);
+        else
+            integrate<float, false><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel,
+                                                                (float2 *)s->acc, (const float2 *)s->acc_full, 1u, 0u, nn, dt, dt,
+                                                                s->p.extras, INTEG_KICK | INTEG_DRIFT);
+        HIPCHK(hipGetLastError());
+        s->cur ^= 1;
+        s->frame += 1;
+        s->acc_valid = false;
+        return NB_OK;
+    }
     if (s->sym_sharded) {
         if (!s->mid_done) { s->in_step = true; return nb_fail(NB_ESTATE, "nb_step_finish: symmetric sharded handle needs nb_step_mid (and the reduce-scatter) first"); }
         s->mid_done = false;
@@ -982,7 +1022,7 @@ extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_step: NULL handle");
     if (nsteps < 0) return nb_fail(NB_EINVAL, "nb_step: nsteps < 0");
-    if (sharded(s)) return nb_fail(NB_ESTATE, "nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish");
+    if (sharded(s) || s->sym_replicated) return nb_fail(NB_ESTATE, "nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish");
     if (s->in_step) return nb_fail(NB_ESTATE, "nb_step: a split step is in flight");
     if (bind(s)) return NB_EHIP;
     const float h = dt > 0.0f ? dt : s->p.dt;
@@ -1240,12 +1280,48 @@ extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
 
 extern "C" int nb_shard_protocol(const nb_sim *s)
 {
+    if (s && s->sym_replicated) return NB_SHARD_ALLREDUCE;
     if (!s || s->i_count == s->n) return NB_SHARD_NONE;
     return s->sym_sharded ? NB_SHARD_SYMMETRIC : NB_SHARD_ALLGATHER;
 }
+
+// In-process all-reduce of the replicated protocol (a host that drives all `count` handles of one run itself):
+// every handle's nb_acc_buffer(0) receives the sum, in rank order, of all handles' partial accelerations — the same
+// bits everywhere, so the replicas stay identical.  Call it between nb_step_begin and nb_step_finish.
+extern "C" int nb_exchange_allreduce(nb_sim *const *sims, int count)
+{
+    if (!sims || count < 1 || count > 64) return nb_fail(NB_EINVAL, "nb_exchange_allreduce: 1..64 handles");
+    PartialPtrs src;
+    for (int a = 0; a < count; ++a) {
+        if (!sims[a] || !sims[a]->sym_replicated || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz ||
+            sims[a]->p.shard_world != count || sims[a]->p.shard_rank != a)
+            return nb_fail(NB_EINVAL, "nb_exchange_allreduce: needs the `count` handles of one replicated (NB_FLAG_SHARD_ALLREDUCE) run, in rank order");
+        if (bind(sims[a])) return NB_EHIP;
+        HIPCHK(hipStreamSynchronize(sims[a]->stream));
+        src.p[a] = sims[a]->acc_full;
+    }
+    for (int o = 0; o < count; ++o) {               // sums into each handle's scratch (its `partial` array) ...
+        nb_sim *s = sims[o];
+        if (bind(s)) return NB_EHIP;
+        for (int r = 0; r < count; ++r)
+            if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+        const uint32_t nn = (uint32_t)s->n, g = (nn + BLOCK - 1) / BLOCK;
+        if (s->fp64) sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (double2 *)s->partial);
+        else         sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float2 *)s->partial);
+        HIPCHK(hipGetLastError());
+    }
+    for (int a = 0; a < count; ++a) { if (bind(sims[a])) return NB_EHIP; HIPCHK(hipStreamSynchronize(sims[a]->stream)); }
+    for (int o = 0; o < count; ++o) {               // ... and only then over the inputs
+        nb_sim *s = sims[o];
+        if (bind(s)) return NB_EHIP;
+        HIPCHK(hipMemcpyAsync(s->acc_full, s->partial, s->n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+    }
+    for (int a = 0; a < count; ++a) { if (bind(sims[a])) return NB_EHIP; HIPCHK(hipStreamSynchronize(sims[a]->stream)); }
+    return NB_OK;
+}
 extern "C" void *nb_acc_buffer(nb_sim *s, int which)
 {
-    if (!s || !s->sym_sharded) return nullptr;
+    if (!s || !(s->sym_sharded || s->sym_replicated)) return nullptr;
     return which == 0 ? s->acc_full : s->acc_owned;
 }
 
@@ -1285,7 +1361,7 @@ extern "C" int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out)
 {
     if (!s || !out) return nb_fail(NB_EINVAL, "nb_sym_plan_info: NULL argument");
     if (out->struct_size != sizeof(nb_sym_info)) return nb_fail(NB_EINVAL, "nb_sym_plan_info: out->struct_size %u != %zu", out->struct_size, sizeof(nb_sym_info));
-    if (s->sym || s->sym_sharded) *out = s->sym_info;
+    if (s->sym || s->sym_sharded || s->sym_replicated) *out = s->sym_info;
     else { memset(out, 0, sizeof *out); out->struct_size = (uint32_t)sizeof(nb_sym_info); out->cus = (uint32_t)s->cus; }
     return NB_OK;
 }
@@ -1303,7 +1379,7 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
-             (int)(s->sym || s->sym_sharded), s->sym_items, s->sym_L, s->sym_items_late,
+             (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;
 }

@@ -18,6 +18,13 @@ the cross-block pairs — which yields a partial acceleration for every particle
     [compute]  force_sym(pairs inside my block) | wait AG | force_sym(my cross-block run) -> acc_partial[n] | RS | kick, drift
     [comm   ]  ... all-gather(x,y) of the previous step ...                                  reduce-scatter(sum)   \\-> all-gather
 
+NB_SHARD_ALLREDUCE (same eligibility, 2-D).  The same pair split, but every rank then integrates ALL particles itself:
+
+    [compute]  force_sym(all my items) -> acc_partial[n] | all-reduce(sum, in place) | kick, drift of all n
+
+one collective per step and no position exchange (every rank holds the whole, bit-identical state); nothing overlaps
+the all-reduce, but there is only that one latency to pay and one force launch instead of three.
+
 ~1.6x fewer VALU cycles per rank for one more latency-bound collective per step
 (``reduce_scatter_tensor``; the all-gather stays hidden behind the local pairs).
 Which of the two is faster on a given node depends on how exposed that second
@@ -42,7 +49,7 @@ import numpy as np
 
 from . import _lib as L
 
-PROTOCOLS = ("auto", "symmetric", "allgather", "tune")
+PROTOCOLS = ("auto", "symmetric", "allgather", "allreduce", "tune")
 
 
 @dataclass(frozen=True)
@@ -125,7 +132,7 @@ def ranks_agree(values: Sequence[int], group=None) -> Tuple[bool, list, list]:
 
 
 def agree_on_fastest(local_seconds: Dict[str, float], group=None,
-                     prefer: Sequence[str] = ("symmetric", "symmetric+late", "symmetric-late", "allgather")):
+                     prefer: Sequence[str] = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather")):
     """Every rank passes its own timing of each candidate (``inf`` = candidate unavailable); the job's time of a
     candidate is the MAX over ranks (the slowest rank sets the step rate).  Returns (winner, {name: job seconds}),
     identical on every rank; ties and near-ties (within 1 %) go to the earlier name in ``prefer``."""
@@ -156,6 +163,7 @@ class DistributedSimulation:
     protocol   "auto"       the library's choice (symmetric where eligible)
                "symmetric"  the symmetric pair split; error if the system is not eligible
                "allgather"  north_star's protocol: one-sided kernels, one all-gather per step
+               "allreduce"  the symmetric pair split with replicated integration: one all-reduce per step
                "tune"       time ``tune_steps`` steps of each candidate on a scratch copy and keep the fastest (the ranks
                             agree by all-reduce): the symmetric split as the library would size it, the same with the
                             held-back "late" local items switched the other way (they hide the reduce-scatter; on by
@@ -219,22 +227,28 @@ class DistributedSimulation:
             # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
             self.acc_full = self.acc_owned = None
             acc_ptrs = None
+            replicated = protocol == "allreduce" and world > 1
             if world > 1 and protocol != "allgather":
                 self.acc_full = torch.zeros((self.plan.n, self._width), dtype=self._dtype, device=self.device)
-                self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
-                acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
+                if replicated:
+                    acc_ptrs = (self.acc_full.data_ptr(), self.acc_full.data_ptr())
+                else:
+                    self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
+                    acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
             kw = dict(self._args)
             kw.update(extra or {})
             if protocol == "allgather":
                 kw["symmetry"] = False
             self.sim = Simulation(
-                bodies, device=self._device_index, i_begin=self.plan.i_begin, i_count=self.plan.i_count,
+                bodies, device=self._device_index,
+                i_begin=0 if replicated else self.plan.i_begin, i_count=self.plan.n if replicated else self.plan.i_count,
                 stream=self.stream.cuda_stream, pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
-                shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, **kw,
+                shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, shard_allreduce=replicated, **kw,
             )
         except (L.NBodyError, RuntimeError, MemoryError) as e:   # keep going to the collective below
             err = e
         self.symmetric = err is None and self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
+        self.replicated = err is None and self.sim.shard_protocol == L.NB_SHARD_ALLREDUCE
         if world > 1:
             info = self.sim.sym_info() if err is None else {}
             vec = [
@@ -257,11 +271,11 @@ class DistributedSimulation:
                                    + (f"; this rank: {err}" if err is not None else "")) from err
         elif err is not None:
             raise err
-        if protocol == "symmetric" and world > 1 and not self.symmetric:
+        if world > 1 and ((protocol == "symmetric" and not self.symmetric) or (protocol == "allreduce" and not self.replicated)):
             self.sim.close()
-            raise RuntimeError("protocol='symmetric' requested but the system is not eligible "
-                               "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096)")
-        self.protocol = "symmetric" if self.symmetric else "allgather"
+            raise RuntimeError(f"protocol='{protocol}' requested but the system is not eligible "
+                               "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096; allreduce: 2-D)")
+        self.protocol = "symmetric" if self.symmetric else "allreduce" if self.replicated else "allgather"
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
@@ -273,11 +287,12 @@ class DistributedSimulation:
         local: Dict[str, float] = {}
         late_default_on = self.plan.world >= 8 and float(self._args.get("sym_late_us", 0.0)) == 0.0
         flipped = ("symmetric-late", {"sym_late_us": -1.0}) if late_default_on else ("symmetric+late", {"sym_late_us": 40.0})
-        cands = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allgather": ("allgather", {})}
+        cands = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allreduce": ("allreduce", {}),
+                 "allgather": ("allgather", {})}
         if float(self._args.get("sym_late_us", 0.0)) != 0.0:      # the caller fixed the late share: nothing to flip
             del cands[flipped[0]]
         for name, (cand, extra) in cands.items():
-            if local.get("symmetric") == float("inf") and cand == "symmetric":
+            if local.get("symmetric") == float("inf") and cand in ("symmetric", "allreduce"):
                 local[name] = float("inf")
                 continue
             try:
@@ -319,6 +334,20 @@ class DistributedSimulation:
         """One sharded step; only enqueues (no host sync)."""
         marks = [] if self._phase_on else None
         t_host = time.perf_counter()
+        if self.replicated:
+            with self.torch.cuda.stream(self.stream):
+                self._mark(marks)
+                self.sim.step_begin(dt)      # all my pairs -> partial acceleration of every particle
+                self._mark(marks)
+                self.dist.all_reduce(self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)   # in place, same bits everywhere
+                self._mark(marks)
+                self.sim.step_finish()       # every rank kicks and drifts all n
+                self._mark(marks)
+            self._host_enqueue_s += time.perf_counter() - t_host
+            self._host_steps += 1
+            if marks is not None:
+                self._phase_events.append(marks)
+            return
         with self.torch.cuda.stream(self.stream):
             self._mark(marks)
             self.sim.step_begin(dt)          # pairs inside my own block / local j-block: overlaps the all-gather still in flight
@@ -364,7 +393,8 @@ class DistributedSimulation:
         all-gather: local | ag_wait | remote_finish.  When the local items run on the side stream
         (``local_on_side_stream``) their time shows up inside `cross`, which joins them."""
         self.wait()
-        names = ("local", "ag_wait", "cross", "reduce_scatter", "finish") if self.symmetric else ("local", "ag_wait", "remote_finish")
+        names = (("local", "ag_wait", "cross", "reduce_scatter", "finish") if self.symmetric else
+                 ("force", "all_reduce", "finish") if self.replicated else ("local", "ag_wait", "remote_finish"))
         tot = {k: 0.0 for k in names}
         for marks in self._phase_events:
             for k, (a, b) in zip(names, zip(marks[:-1], marks[1:])):
@@ -380,9 +410,11 @@ class DistributedSimulation:
 
     # -- host views ---------------------------------------------------------------
     def sync(self) -> np.ndarray:
-        """Owned block as Body records (each GPU copies back only its block)."""
+        """Owned block as Body records (each GPU copies back only its block; a replicated handle holds all n and
+        returns its rank's block of them, so the result is the same in every protocol)."""
         self.wait()
-        return self.sim.sync()
+        b = self.sim.sync()
+        return b[self.plan.i_begin:self.plan.i_end] if self.replicated else b
 
     def gather_bodies(self) -> Optional[np.ndarray]:
         """All blocks on every rank (host-side object gather; for tests / dumps)."""
@@ -396,7 +428,7 @@ class DistributedSimulation:
     def energy(self) -> tuple:
         self.wait()
         k, u = self.sim.energy()
-        if self.plan.world > 1:
+        if self.plan.world > 1 and not self.replicated:       # a replicated handle already holds the total
             t = self.torch.tensor([k, u], dtype=self.torch.float64, device=self.device)
             if self.dist.get_backend(self.group) != "nccl":
                 t = t.cpu()

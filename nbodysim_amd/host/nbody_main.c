@@ -12,6 +12,7 @@
  *              [-shards P]   P sharded handles driven from this one process (device r mod #GPUs),
  *                            exchanged with nb_exchange_positions: multi-GPU without RCCL
  *              [-no-symmetry] one-sided kernels / all-gather protocol (nb_params.flags)
+ *              [-allreduce]  with -shards: the replicated protocol (every handle integrates all n; in-process all-reduce)
  *              [-late-us US] sharded symmetric protocol: local work held back for the side stream (nb_params.sym_late_us)
  * -load FILE restarts from a dump: eps, dt, precision, rsqrt mode, sum order, integrator and extras come from its
  * header unless the command line gives them (options are applied in order, so put -load first to override).
@@ -68,6 +69,7 @@ int main(int argc, char **argv)
             p.sum_order = fp.sum_order; p.integrator = fp.integrator; p.extras = fp.extras; p.dims = fp.dims;
         }
         else if (!strcmp(argv[i], "-no-symmetry")) p.flags |= NB_FLAG_NO_SYMMETRY;
+        else if (!strcmp(argv[i], "-allreduce")) p.flags |= NB_FLAG_SHARD_ALLREDUCE;
         else if (!strcmp(argv[i], "-late-us") && i + 1 < argc) p.sym_late_us = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-shards") && i + 1 < argc) shards = atoi(argv[++i]);
@@ -99,11 +101,13 @@ int main(int argc, char **argv)
         for (int r = 0; r < shards; ++r) {
             nb_params q = p;
             q.i_begin = (uint64_t)r * blk; q.i_count = blk; q.device = ndev > 0 ? r % ndev : 0;
+            if (p.flags & NB_FLAG_SHARD_ALLREDUCE) { q.i_begin = 0; q.i_count = n; }     /* replicated: every handle integrates all n */
             q.shard_rank = r; q.shard_world = shards;   /* lets the library pick the symmetric protocol where it applies */
             h[r] = nb_create(bodies, n, &q);
             if (!h[r]) DIE("nb_create(shard %d): %s", r, nb_last_error());
         }
         const int symmetric = nb_shard_protocol(h[0]) == NB_SHARD_SYMMETRIC;
+        const int replicated = nb_shard_protocol(h[0]) == NB_SHARD_ALLREDUCE;
         char desc0[1024];
         CHECK(nb_describe(h[0], desc0, sizeof desc0));
         printf("shard 0: %s\n", desc0);
@@ -114,12 +118,14 @@ int main(int argc, char **argv)
                 for (int r = 0; r < shards; ++r) CHECK(nb_step_mid(h[r]));
                 CHECK(nb_exchange_accelerations(h, shards));
             }
+            if (replicated) CHECK(nb_exchange_allreduce(h, shards));
             for (int r = 0; r < shards; ++r) CHECK(nb_step_finish(h[r]));
-            CHECK(nb_exchange_positions(h, shards));
+            if (!replicated) CHECK(nb_exchange_positions(h, shards));
         }
         const double pers = (now_s() - t0s) / steps;
-        for (int r = 0; r < shards; ++r) CHECK(nb_sync(h[r], bodies + (size_t)r * blk));
-        printf("protocol=%s ", symmetric ? "symmetric" : "allgather");
+        if (replicated) CHECK(nb_sync(h[0], bodies));                 /* every handle holds the whole state */
+        else for (int r = 0; r < shards; ++r) CHECK(nb_sync(h[r], bodies + (size_t)r * blk));
+        printf("protocol=%s ", symmetric ? "symmetric" : replicated ? "allreduce" : "allgather");
         printf("shards=%d on %d device(s): frame=%llu  %.3f ms/step  %.3e pair interactions/s\n", shards, ndev,
                (unsigned long long)nb_frame(h[0]), pers * 1e3, (double)n * (double)n / pers);
         printf("body[0]: pos=(%.6f, %.6f) vel=(%.6f, %.6f)\n", bodies[0].pos.x, bodies[0].pos.y, bodies[0].vel.x, bodies[0].vel.y);

@@ -206,8 +206,10 @@ def test_protocol_autotune_and_phase_report_two_ranks(tmp_path, n, dims, precisi
     reps = [json.loads((tmp_path / f"tune_{r}.json").read_text()) for r in range(world)]
     assert reps[0]["tuning"] == reps[1]["tuning"] and reps[0]["protocol"] == reps[1]["protocol"]
     t = reps[0]["tuning"]
-    assert set(t["ms_per_step"]) == {"symmetric", "symmetric+late", "allgather"} and all(0 < v < 1e4 for v in t["ms_per_step"].values())
-    want = ("local", "ag_wait", "cross", "reduce_scatter", "finish") if reps[0]["protocol"] == "symmetric" else ("local", "ag_wait", "remote_finish")
+    assert set(t["ms_per_step"]) == {"symmetric", "symmetric+late", "allreduce", "allgather"}
+    assert all(v is None or 0 < v < 1e4 for v in t["ms_per_step"].values()) and (t["ms_per_step"]["allreduce"] is None) == (dims == 3)
+    want = {"symmetric": ("local", "ag_wait", "cross", "reduce_scatter", "finish"), "allreduce": ("force", "all_reduce", "finish"),
+            "allgather": ("local", "ag_wait", "remote_finish")}[reps[0]["protocol"]]
     for r in reps:
         assert r["phases"]["steps"] == 4 and all(k in r["phases"] and r["phases"][k] >= 0 for k in want)
         assert r["phases"]["host_enqueue"] > 0 and r["phases"]["stream_total"] > 0
@@ -218,3 +220,51 @@ def test_protocol_autotune_and_phase_report_two_ranks(tmp_path, n, dims, precisi
         ref = sim.sync()["pos"].astype(np.float64)
     pos = np.concatenate([np.load(tmp_path / f"tpos_{r}.npy") for r in range(world)])
     assert _rel(pos.reshape(n, -1)[:, :dims], ref.reshape(n, -1)[:, :dims]) < (2e-6 if precision == "fp32" else 1e-7)
+
+
+def _allreduce_worker(rank, world, port, n, precision, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd.dist import DistributedSimulation
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with DistributedSimulation(nb.plummer_2d(n, 42), eps=0.05, precision=precision, device_index=0, protocol="allreduce") as sim:
+            assert sim.protocol == "allreduce" and sim.replicated
+            k0, u0 = sim.energy()
+            sim.profile_phases(True)
+            sim.advance(5, 1e-3)
+            rep = sim.phase_report()
+            assert set(("force", "all_reduce", "finish")) <= set(rep) and rep["steps"] == 5
+            k1, u1 = sim.energy()
+            mine = sim.sync().copy()
+            assert mine.shape[0] == n // world and sim.frame == 5
+            np.save(Path(out_dir) / f"arpos_{rank}.npy", mine["pos"])
+            np.save(Path(out_dir) / f"arenergy_{rank}.npy", np.array([k0 + u0, k1 + u1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,precision", [(2, "fp32"), (4, "fp32"), (2, "fp64")])
+def test_allreduce_protocol_over_gloo_matches_single_handle(tmp_path, world, precision):
+    import torch.multiprocessing as mp
+    n = 32768
+    mp.spawn(_allreduce_worker, args=(world, _free_port(), n, precision, str(tmp_path)), nprocs=world, join=True)
+    import nbodysim_amd as nb
+    with nb.Simulation(nb.plummer_2d(n, 42), eps=0.05, precision=precision) as sim:
+        e0 = sum(sim.energy())
+        sim.advance(5, 1e-3)
+        ref = sim.sync()["pos"].astype(np.float64)
+        e1 = sum(sim.energy())
+    pos = np.concatenate([np.load(tmp_path / f"arpos_{r}.npy") for r in range(world)])
+    assert _rel(pos, ref) < (2e-6 if precision == "fp32" else 1e-7)
+    for r in range(world):
+        e = np.load(tmp_path / f"arenergy_{r}.npy")                 # every rank holds the total: no all-reduce of the energy
+        assert abs(e[0] - e0) < 1e-9 * abs(e0) and abs(e[1] - e1) < 1e-6 * abs(e1)

@@ -220,3 +220,41 @@ def test_config5_fp64_headline_size_single_and_split_energy_vs_cpu(headline_ic, 
     assert abs((k1 + u1 - k0 - u0) / (k0 + u0)) < 1e-5
     pos = np.stack([st["x"], st["y"]], 1)
     assert max_rel(single["pos"], pos) < 2e-7 and max_rel(out["pos"], pos) < 2e-7   # float output records
+
+
+@pytest.mark.parametrize("precision,parts", [("fp32", 4), ("fp64", 2), ("fp32", 8)])
+def test_replicated_allreduce_protocol_in_process(precision, parts):
+    """NB_SHARD_ALLREDUCE: every rank evaluates its share of the unordered pairs, the partial accelerations of ALL
+    particles are all-reduced (here in-process, nb_exchange_allreduce) and every rank integrates everything: the
+    replicas stay bit-identical to each other and follow the unsharded handle to rounding."""
+    lib = nb.load()
+    n, steps = 131072, 3
+    ic = nb.plummer_2d(n, 6)
+    with nb.Simulation(ic, eps=0.02, precision=precision) as sim:
+        sim.advance(steps, DT)
+        whole = sim.sync().copy()
+        e_whole = sum(sim.energy())
+    sims = [nb.Simulation(ic, eps=0.02, precision=precision, shard_rank=r, shard_world=parts, shard_allreduce=True) for r in range(parts)]
+    try:
+        assert all(s.shard_protocol == L.NB_SHARD_ALLREDUCE and s.i_count == n for s in sims)
+        infos = [s.sym_info() for s in sims]
+        assert sum(i["units_cross"] for i in infos) == infos[0]["cross_units_total"] and all(i["items_late"] == 0 for i in infos)
+        with pytest.raises(nb.NBodyError):
+            sims[0].advance(1, DT)                                  # needs the exchange: nb_step refuses
+        handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
+        for _ in range(steps):
+            for s in sims:
+                s.step_begin(DT)
+            L.check("nb_exchange_allreduce", lib.nb_exchange_allreduce(handles, parts))
+            for s in sims:
+                s.step_finish()
+        outs = [s.sync().copy() for s in sims]
+        energies = [sum(s.energy()) for s in sims]
+    finally:
+        for s in sims:
+            s.close()
+    for o in outs[1:]:                                              # same bits on every rank
+        assert o.tobytes() == outs[0].tobytes()
+    tol = (2e-6, 2e-5) if precision == "fp32" else (2e-7, 2e-7)
+    assert max_rel(outs[0]["pos"], whole["pos"]) < tol[0] and max_rel(outs[0]["vel"], whole["vel"]) < tol[1]
+    assert all(abs(e - e_whole) < (1e-5 if precision == "fp32" else 1e-10) * abs(e_whole) for e in energies)

@@ -83,7 +83,8 @@ def test_sync_into_page_locked_host_memory_is_identical():
             L.check("nb_host_unregister", lib.nb_host_unregister(pinned.ctypes.data))
 
 
-@pytest.mark.parametrize("n,protocol,late_us", [(8192, "allgather", None), (65536, "symmetric", None), (65536, "symmetric", "40")])
+@pytest.mark.parametrize("n,protocol,late_us", [(8192, "allgather", None), (65536, "symmetric", None), (65536, "symmetric", "40"),
+                                                (65536, "allreduce", None)])
 def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, protocol, late_us):
     """`nbody_main -shards 4`: four sharded handles in one C process, exchanged with
     nb_exchange_positions / nb_exchange_accelerations (the multi-GPU-without-RCCL host);
@@ -91,10 +92,12 @@ def test_c_driver_with_in_process_shards_matches_single_handle(tmp_path, n, prot
     exe = _host_program("nbody_main")
     dump = tmp_path / "sh.nbd"
     extra = ["-late-us", late_us] if late_us else []   # hold local items back for the side stream (default from 8 ranks on)
+    if protocol == "allreduce":
+        extra = ["-allreduce"]                            # replicated integration, in-process all-reduce
     r = subprocess.run([str(exe), "-n", str(n), "-s", "6", "-shards", "4", "-eps", "0.05", "-dump", str(dump)] + extra,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert ("late=0" not in r.stdout) == bool(late_us) or protocol == "allgather"
+    assert ("late=0" not in r.stdout) == bool(late_us) or protocol != "symmetric"
     assert "shards=4" in r.stdout and "frame=6" in r.stdout and f"protocol={protocol}" in r.stdout
     back, frame, _ = nb.read_bodies(dump)
     with nb.Simulation(nb.plummer_2d(n, 42), eps=0.05) as sim:
