@@ -174,7 +174,7 @@ class DistributedSimulation:
 
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
                  order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
-                 protocol: str = "auto", tune_steps: int = 6, tune_dt: float = 1e-3, **sim_kwargs):
+                 protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, **sim_kwargs):
         import torch
         import torch.distributed as dist
 
