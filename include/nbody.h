@@ -264,7 +264,7 @@ enum { NB_POS_CURRENT = 0, NB_POS_NEXT = 1 };
  *                        it runs while the reduce-scatter is in flight and nb_step_finish adds its result to
  *                        nb_acc_buffer(1) — nothing changes for the host.)
  *   NB_SHARD_ALLREDUCE   (NB_FLAG_SHARD_ALLREDUCE, shard_world > 1, i_begin = 0, i_count = n, otherwise as
- *                        NB_SHARD_SYMMETRIC; 2-D): every rank evaluates its 1/world of the unordered pairs and then
+ *                        NB_SHARD_SYMMETRIC): every rank evaluates its 1/world of the unordered pairs and then
  *                        integrates ALL n particles itself: begin = all its items, then its partial acceleration of
  *                        every particle into nb_acc_buffer(0); the host ALL-REDUCES that buffer in place (sum; every
  *                        rank must receive the same bits, which ring / tree all-reduces deliver); finish = kick, drift of

@@ -236,7 +236,7 @@ static bool want_sym(const nb_sim *s)          // single handle owns everything
 static bool want_sym_replicated(const nb_sim *s)  // rank of a run that all-reduces accelerations and integrates everything everywhere
 {
     const size_t w = (size_t)s->p.shard_world;
-    return (s->p.flags & NB_FLAG_SHARD_ALLREDUCE) && s->p.shard_world > 1 && s->i_count == s->n && !s->dims3 &&
+    return (s->p.flags & NB_FLAG_SHARD_ALLREDUCE) && s->p.shard_world > 1 && s->i_count == s->n &&
            s->p.integrator == NB_INTEGRATOR_KICK_DRIFT && sym_eligible(s) && s->n / w >= 2 * (size_t)SYM_SB && s->n % (w * SYM_SB) == 0;
 }
 
@@ -931,7 +931,13 @@ extern "C" int nb_step_finish(nb_sim *s)
         const uint32_t nn = (uint32_t)s->n, g = (nn + BLOCK - 1) / BLOCK;
         const int nxt = s->cur ^ 1;
         const float dt = s->pending_dt;
-        if (s->fp64)
+        if (s->dims3 && s->fp64)
+            integrate3<double><<<g, BLOCK, 0, s->stream>>>((const double4 *)s->pos[s->cur], (double4 *)s->pos[nxt], (double4 *)s->vel, (double4 *)s->acc,
+                                                           (const double4 *)s->acc_full, 1u, 0u, nn, (double)dt, (double)dt, INTEG_KICK | INTEG_DRIFT);
+        else if (s->dims3)
+            integrate3<float><<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (float4 *)s->pos[nxt], (float4 *)s->vel, (float4 *)s->acc,
+                                                          (const float4 *)s->acc_full, 1u, 0u, nn, dt, dt, INTEG_KICK | INTEG_DRIFT);
+        else if (s->fp64)
             integrate<double, false><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel,
                                                                  (double2 *)s->acc, (const double2 *)s->acc_full, 1u, 0u, nn,
                                                                  (double)dt, (double)dt, s->p.extras, INTEG_KICK | INTEG_DRIFT);
@@ -1306,8 +1312,10 @@ extern "C" int nb_exchange_allreduce(nb_sim *const *sims, int count)
         for (int r = 0; r < count; ++r)
             if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
         const uint32_t nn = (uint32_t)s->n, g = (nn + BLOCK - 1) / BLOCK;
-        if (s->fp64) sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (double2 *)s->partial);
-        else         sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float2 *)s->partial);
+        if (s->dims3 && s->fp64) sum_partials<double4><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (double4 *)s->partial);
+        else if (s->dims3)       sum_partials<float4><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float4 *)s->partial);
+        else if (s->fp64)        sum_partials<double2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (double2 *)s->partial);
+        else                     sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float2 *)s->partial);
         HIPCHK(hipGetLastError());
     }
     for (int a = 0; a < count; ++a) { if (bind(sims[a])) return NB_EHIP; HIPCHK(hipStreamSynchronize(sims[a]->stream)); }

@@ -18,7 +18,7 @@ the cross-block pairs — which yields a partial acceleration for every particle
     [compute]  force_sym(pairs inside my block) | wait AG | force_sym(my cross-block run) -> acc_partial[n] | RS | kick, drift
     [comm   ]  ... all-gather(x,y) of the previous step ...                                  reduce-scatter(sum)   \\-> all-gather
 
-NB_SHARD_ALLREDUCE (same eligibility, 2-D).  The same pair split, but every rank then integrates ALL particles itself:
+NB_SHARD_ALLREDUCE (same eligibility).  The same pair split, but every rank then integrates ALL particles itself:
 
     [compute]  force_sym(all my items) -> acc_partial[n] | all-reduce(sum, in place) | kick, drift of all n
 
@@ -274,7 +274,7 @@ class DistributedSimulation:
         if world > 1 and ((protocol == "symmetric" and not self.symmetric) or (protocol == "allreduce" and not self.replicated)):
             self.sim.close()
             raise RuntimeError(f"protocol='{protocol}' requested but the system is not eligible "
-                               "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096; allreduce: 2-D)")
+                               "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096)")
         self.protocol = "symmetric" if self.symmetric else "allreduce" if self.replicated else "allgather"
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica

@@ -152,6 +152,36 @@ def _run_sharded3(ic, parts, steps, dt, **kw):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_3d_replicated_allreduce_protocol(precision):
+    """NB_SHARD_ALLREDUCE in 3-D: four in-process handles, each integrating all n after the all-reduce."""
+    lib = nb.load()
+    n, parts, steps = 65536, 4, 3
+    ic = nb.plummer_3d(n, 9).view(nb.BODY3_DTYPE)
+    with nb.Simulation(ic, dims=3, eps=0.02, precision=precision) as sim:
+        sim.advance(steps, 1e-3)
+        whole = sim.sync().copy()
+    sims = [nb.Simulation(ic, dims=3, eps=0.02, precision=precision, shard_rank=r, shard_world=parts, shard_allreduce=True) for r in range(parts)]
+    try:
+        assert all(s.shard_protocol == L.NB_SHARD_ALLREDUCE for s in sims)
+        handles = (ctypes.c_void_p * parts)(*[s._h for s in sims])
+        for _ in range(steps):
+            for s in sims:
+                s.step_begin(1e-3)
+            L.check("nb_exchange_allreduce", lib.nb_exchange_allreduce(handles, parts))
+            for s in sims:
+                s.step_finish()
+        outs = [s.sync().copy() for s in sims]
+    finally:
+        for s in sims:
+            s.close()
+    for o in outs[1:]:
+        assert np.array_equal(o["pos"].view(np.uint32), outs[0]["pos"].view(np.uint32))
+    tol = (2e-6, 2e-5) if precision == "fp32" else (2e-7, 2e-7)
+    assert max_rel(outs[0]["pos"], whole["pos"]) < tol[0] and max_rel(outs[0]["vel"], whole["vel"]) < tol[1]
+    assert outs[0]["pos"][:, 2].any()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
 @pytest.mark.parametrize("protocol,parts,late_us", [("symmetric", 2, -1.0), ("symmetric", 4, 40.0), ("allgather", 4, 0.0)])
 def test_3d_sharded_handles_match_unsharded(precision, protocol, parts, late_us):
     n, steps = 65536, 3
