@@ -186,8 +186,8 @@ int nb_host_register(void *ptr, size_t bytes);
 int nb_host_unregister(void *ptr);
 
 /* Positions only (8 bytes/body instead of 64): the fast path for a viewer that
- * only draws (main.cpp:623-627 consumer).  out holds 2*i_count floats (x,y).
- * For NB_FP64 handles values are rounded to float. */
+ * only draws (main.cpp:623-627 consumer).  out holds 2*i_count floats (x,y) — 3*i_count
+ * (x,y,z) for a dims = 3 handle.  For NB_FP64 handles values are rounded to float. */
 int nb_sync_positions(nb_sim *s, float *out_xy);
 
 /* Pipelined snapshot for a caller that does `step(); copy bodies` every frame (main.cpp:621-627) and can take the

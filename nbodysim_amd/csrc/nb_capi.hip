@@ -1169,21 +1169,25 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
 extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
 {
     if (!s || !out_xy) return nb_fail(NB_EINVAL, "nb_sync_positions: NULL argument");
-    if (s->dims3) return nb_fail(NB_EINVAL, "nb_sync_positions: 2-D handles only (use nb_sync for dims = 3)");
     if (bind(s)) return NB_EHIP;
     if (nb_snapshot_wait(s)) return nb_last_error_code();
     if (ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
-    if (s->fp64) {
+    const size_t bytes = s->i_count * (s->dims3 ? 3 : 2) * sizeof(float);       // (x, y) or (x, y, z) per body
+    if (s->dims3) {
+        if (s->fp64) pack_positions3<double><<<g, BLOCK, 0, s->stream>>>((float *)s->aos_dev, (const double4 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
+        else         pack_positions3<float><<<g, BLOCK, 0, s->stream>>>((float *)s->aos_dev, (const float4 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, bytes, hipMemcpyDeviceToHost, s->stream));
+    } else if (s->fp64) {
         pack_positions<double><<<g, BLOCK, 0, s->stream>>>((float2 *)s->aos_dev, (const double2 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, s->i_count * sizeof(float2), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, bytes, hipMemcpyDeviceToHost, s->stream));
     } else {
-        HIPCHK(hipMemcpyAsync(s->staging, (const float2 *)s->pos[s->cur] + s->i_begin, s->i_count * sizeof(float2),
-                              hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->staging, (const float2 *)s->pos[s->cur] + s->i_begin, bytes, hipMemcpyDeviceToHost, s->stream));
     }
     HIPCHK(hipStreamSynchronize(s->stream));
-    memcpy(out_xy, s->staging, s->i_count * sizeof(float2));
+    memcpy(out_xy, s->staging, bytes);
     return NB_OK;
 }
 

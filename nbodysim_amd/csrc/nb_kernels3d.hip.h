@@ -540,6 +540,19 @@ void pack_bodies3(BodyRec *__restrict__ aos, const typename vec4_of<real>::type 
     aos[li] = r;
 }
 
+// positions only, as packed (x, y, z) floats: the viewer's fast path in 3-D (12 bytes per body)
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void pack_positions3(float *__restrict__ out, const typename vec4_of<real>::type *__restrict__ pos, uint32_t i_begin, uint32_t i_count)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    if (li >= i_count) return;
+    const auto p = pos[i_begin + li];
+    out[3 * (size_t)li + 0] = (float)p.x;
+    out[3 * (size_t)li + 1] = (float)p.y;
+    out[3 * (size_t)li + 2] = (float)p.z;
+}
+
 // energy in fp64: K = sum m v^2 / 2, U = - sum_i m_i sum_{j > i} m_j / sqrt(r^2 + eps^2) (every unordered pair once)
 template <typename real>
 __global__ __launch_bounds__(BLOCK)

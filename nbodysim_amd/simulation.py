@@ -138,7 +138,7 @@ class Simulation:
         L.check("nb_snapshot_wait", self._lib.nb_snapshot_wait(self._h))
 
     def positions(self) -> np.ndarray:
-        out = np.empty((self.i_count, 2), dtype=np.float32)
+        out = np.empty((self.i_count, 3 if self._params.dims == 3 else 2), dtype=np.float32)
         L.check("nb_sync_positions", self._lib.nb_sync_positions(self._h, out.ctypes.data))
         return out
 

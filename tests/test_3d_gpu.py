@@ -215,3 +215,13 @@ def test_3d_kdk_integrator_matches_numpy_leapfrog(nbo):
         st["vx"] += 0.5 * dt * ax; st["vy"] += 0.5 * dt * ay; st["vz"] += 0.5 * dt * az
     assert max_rel(got["pos"], np.stack([st["x"], st["y"], st["z"]], 1)) < 1e-5
     assert max_rel(got["vel"], np.stack([st["vx"], st["vy"], st["vz"]], 1)) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_3d_positions_fast_path(precision):
+    ic = nb.plummer_3d(5000, 2).view(nb.BODY3_DTYPE)
+    with nb.Simulation(ic, eps=0.05, dims=3, precision=precision) as sim:
+        sim.advance(3, 1e-3)
+        full = sim.sync()["pos"].copy()
+        xyz = sim.positions()
+    assert xyz.shape == (5000, 3) and np.array_equal(xyz, full)
