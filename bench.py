@@ -321,6 +321,19 @@ def main() -> None:
             g.wait()
             gms, gl = g.profile_read()
         general = {"avg_launch_ms": gms / gl, "launches": gl}
+    # second secondary figure: north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of
+    # 256 — on the same workload (the symmetric kernel is this repo's faster replacement for it)
+    lds_tiled = None
+    if world == 1 and rank == 0 and not args.no_secondary and not args.no_symmetry and not args.no_kernel_events:
+        with nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
+                           symmetry=False, uniform_mass=not args.general_mass) as g:
+            g.advance(2, DT)
+            g.wait()
+            g.profile(True)
+            g.advance(max(4, args.steps // 4), DT)
+            g.wait()
+            lms, ll = g.profile_read()
+        lds_tiled = {"avg_launch_ms": lms / ll, "launches": ll}
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)
@@ -423,6 +436,10 @@ def main() -> None:
                 "general_mass": ({**general, "frac": flop_per_pair * pairs_per_step / (general["avg_launch_ms"] * 1e-3) / 1e12 / peak,
                                   "note": "same kernel without the equal-mass specialisation (individual masses): untimed secondary run"}
                                  if general else None),
+                "one_sided_lds_tiled": ({**lds_tiled, "kernel": "force_tiled" + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64"),
+                                         "frac": flop_per_pair * pairs_per_step / (lds_tiled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
+                                         "note": "north_star's kernel design (every ordered pair, j-tiles of 256 in LDS) on the same workload: untimed secondary run"}
+                                        if lds_tiled else None),
                 "note": "fp32 vector-ALU bound (no dense contraction for MFMA; the f32 MFMA peak equals the vector peak, 157.3 TF); "
                         "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B: HBM is not the bound, the slab traffic is the "
                         "price of evaluating every pair once with plain stores (no atomics, bit-reproducible)",

@@ -43,6 +43,8 @@ def test_bench_line_contract():
     g = rf["general_mass"]
     assert g["avg_launch_ms"] > rf["avg_launch_ms"] and 0 < g["frac"] < rf["frac"]   # individual masses: 12 + 2 ops per body
     assert {"nproc", "affinity", "cgroup_cpus", "model"} <= set(d["cpu_baseline"]["host"])
+    t = rf["one_sided_lds_tiled"]
+    assert t["kernel"] == "force_tiled_f32" and t["avg_launch_ms"] > rf["avg_launch_ms"] and 0.3 < t["frac"] < rf["frac"]
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb
