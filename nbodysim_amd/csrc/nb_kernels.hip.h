@@ -608,8 +608,9 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 // (+2 mul with individual masses) for 128 ordered interactions per wave.
 // ---------------------------------------------------------------------------
 constexpr int SYM_P64 = 8;    // stationary particles per lane: 64 * 8 = SYM_WT per wave
-__device__ __forceinline__ double rsqrt_f64(double x);
-__device__ __forceinline__ double rsqrt3_f64(double x);
+__device__ __forceinline__ double vgpr_const(double k);
+__device__ __forceinline__ double rsqrt_f64(double x, double k0375);
+__device__ __forceinline__ double rsqrt3_f64(double x, double k15, double k1875);
 
 __device__ __forceinline__ double lane_rot64(double v, int addr)
 {
@@ -630,6 +631,7 @@ void sym_chunks_f64(const double2 *__restrict__ pos, const double *__restrict__ 
 {
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    const double k15 = vgpr_const(1.5), k1875 = vgpr_const(1.875);
     double xq = PAD_XY64, yq = PAD_XY64, mq = 0.0;
     {
         const uint32_t j = c0 * SYM_CH + lane;
@@ -650,7 +652,7 @@ void sym_chunks_f64(const double2 *__restrict__ pos, const double *__restrict__ 
             for (int p = 0; p < SYM_P64; ++p) {
                 const double dx = xq - xi[p], dy = yq - yi[p];
                 const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
-                const double inv3 = rsqrt3_f64(r2);
+                const double inv3 = rsqrt3_f64(r2, k15, k1875);
                 if constexpr (UM) {
                     ax[p] = __builtin_fma(inv3, dx, ax[p]);
                     ay[p] = __builtin_fma(inv3, dy, ay[p]);
@@ -782,25 +784,36 @@ void force_seq_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 // register slot (P slots), same tiling; 1/sqrt from v_rsq_f64 refined by one
 // third-order step (relative error ~1e-16 after refinement).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double rsqrt_f64(double x)
+// A floating-point constant held in a VGPR pair for the whole kernel.  gfx950 (GFX9 encoding) cannot put a 64-bit
+// literal into a VOP3 v_fma_f64, so `fma(e, 1.875, 1.5)` would otherwise be compiled as v_mov_b32 x2 (re-materialising
+// 1.5 in the destination) + v_fmac_f64 with the literal 1.875: two extra VALU instructions per pair body, 5 % of the
+// fp64 force kernels.  The empty asm makes the value opaque; every kernel creates its constants once, before its
+// loops (k15 = vgpr_const(1.5) ...), and hands them down.
+__device__ __forceinline__ double vgpr_const(double k)
+{
+    asm("" : "+v"(k));
+    return k;
+}
+
+__device__ __forceinline__ double rsqrt_f64(double x, double k0375)
 {
     double y = __builtin_amdgcn_rsq(x);            // v_rsq_f64, ~2^-26 relative
     const double e = __builtin_fma(-x * y, y, 1.0);  // 1 - x y^2
     // y * (1 + e/2 + 3e^2/8): third-order correction
-    const double c = __builtin_fma(e, 0.375, 0.5);
+    const double c = __builtin_fma(e, k0375, 0.5);
     return __builtin_fma(y * e, c, y);
 }
 
 // x^(-3/2) in one go: with y = v_rsq_f64(x) and e = 1 - x y^2,  x^(-3/2) = y^3 (1 - e)^(-3/2)
 // = y^3 (1 + 3e/2 + 15e^2/8 + O(e^3)),  e ~ 1e-7: six operations after the v_rsq_f64 where
 // rsqrt_f64 followed by inv * inv * inv takes seven (the force kernels are VALU-bound: -5 %).
-__device__ __forceinline__ double rsqrt3_f64(double x)
+__device__ __forceinline__ double rsqrt3_f64(double x, double k15, double k1875)
 {
     const double y = __builtin_amdgcn_rsq(x);
     const double y2 = y * y;
     const double e = __builtin_fma(-x, y2, 1.0);
     const double y3 = y2 * y;
-    const double c = __builtin_fma(e, 1.875, 1.5);
+    const double c = __builtin_fma(e, k1875, k15);
     return __builtin_fma(y3 * e, c, y3);
 }
 
@@ -816,6 +829,7 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
     constexpr uint32_t IT = BLOCK * P;
     struct alignas(16) JD { double x, y, m, pad; };
     __shared__ JD tile[2][TJ];
+    const double k15 = vgpr_const(1.5), k1875 = vgpr_const(1.875);
 
     const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
     if (!tm.valid) return;
@@ -855,10 +869,10 @@ void force_tiled_f64(const double2 *__restrict__ pos, const double *__restrict__
                 double r2, inv3;
                 if constexpr (GUARD) {
                     r2 = __builtin_fma(dy, dy, dx * dx);
-                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2) : 0.0;
+                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2, k15, k1875) : 0.0;
                 } else {
                     r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
-                    inv3 = rsqrt3_f64(r2);
+                    inv3 = rsqrt3_f64(r2, k15, k1875);
                 }
                 const double s = mj * inv3;
                 ax[p] = __builtin_fma(s, dx, ax[p]);
@@ -1015,6 +1029,7 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
     const bool live = li < i_count;
     const uint32_t gi = i_begin + (live ? li : i_count - 1);
     const double xi = (double)pos[gi].x, yi = (double)pos[gi].y;
+    const double k0375 = vgpr_const(0.375);
     double u = 0.0;
     const uint32_t first = ((i_begin + blockIdx.x * BLOCK) / TJ) * TJ;      // j-tile holding the block's first particle
     for (uint32_t j0 = first; j0 < n; j0 += TJ) {
@@ -1028,7 +1043,7 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
             const double dx = tile[jj].x - xi, dy = tile[jj].y - yi;
             const double r2 = __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2));
             const double w = (j0 + jj > gi) ? tile[jj].m : 0.0;
-            u = __builtin_fma(w, rsqrt_f64(r2), u);      // v_rsq_f64 + third-order step: 1.4e-16 relative
+            u = __builtin_fma(w, rsqrt_f64(r2, k0375), u);      // v_rsq_f64 + third-order step: 1.4e-16 relative
         }
     }
     double k = 0.0, uu = 0.0;

@@ -304,6 +304,7 @@ void force_tiled3_f64(const double4 *__restrict__ pos, double4 *__restrict__ par
 {
     constexpr uint32_t IT = BLOCK * P;
     __shared__ double4 tile[2][TJ];
+    const double k15 = vgpr_const(1.5), k1875 = vgpr_const(1.875);
     const TileMap tm = decode_block(blockIdx.x, i_tiles, js);
     if (!tm.valid) return;
     const uint32_t t = threadIdx.x;
@@ -339,10 +340,10 @@ void force_tiled3_f64(const double4 *__restrict__ pos, double4 *__restrict__ par
                 double r2, inv3;
                 if constexpr (GUARD) {
                     r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2) : 0.0;
+                    inv3 = r2 > 0.0 ? rsqrt3_f64(r2, k15, k1875) : 0.0;
                 } else {
                     r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-                    inv3 = rsqrt3_f64(r2);
+                    inv3 = rsqrt3_f64(r2, k15, k1875);
                 }
                 const double sc = q.w * inv3;
                 ax[p] = __builtin_fma(sc, dx, ax[p]);
@@ -374,6 +375,7 @@ void sym3_chunks_f64(const double4 *__restrict__ pos, double4 *__restrict__ slab
 {
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    const double k15 = vgpr_const(1.5), k1875 = vgpr_const(1.875);
     double xq = PAD_XY64, yq = PAD_XY64, zq = PAD_XY64, mq = 0.0;
     {
         const uint32_t j = c0 * SYM_CH + lane;
@@ -394,7 +396,7 @@ void sym3_chunks_f64(const double4 *__restrict__ pos, double4 *__restrict__ slab
             for (int p = 0; p < SYM_P64; ++p) {
                 const double dx = xq - xi[p], dy = yq - yi[p], dz = zq - zi[p];
                 const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-                const double inv3 = rsqrt3_f64(r2);
+                const double inv3 = rsqrt3_f64(r2, k15, k1875);
                 double si = inv3, sj = inv3;
                 if constexpr (!UM) { si = mq * inv3; sj = mi[p] * inv3; }
                 ax[p] = __builtin_fma(si, dx, ax[p]);
@@ -567,6 +569,7 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
     const uint32_t gi = i_begin + (live ? li : i_count - 1);
     const auto pi = pos[gi];
     const double xi = pi.x, yi = pi.y, zi = pi.z;
+    const double k0375 = vgpr_const(0.375);
     double u = 0.0;
     const uint32_t first = ((i_begin + blockIdx.x * BLOCK) / TJ) * TJ;
     for (uint32_t j0 = first; j0 < n; j0 += TJ) {
@@ -580,7 +583,7 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
             const double dx = tile[jj].x - xi, dy = tile[jj].y - yi, dz = tile[jj].z - zi;
             const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
             const double wgt = (j0 + jj > gi) ? tile[jj].m : 0.0;
-            u = __builtin_fma(wgt, rsqrt_f64(r2), u);
+            u = __builtin_fma(wgt, rsqrt_f64(r2, k0375), u);
         }
     }
     double k = 0.0, uu = 0.0;

@@ -23,6 +23,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 n_run = int(sys.argv[2]) if len(sys.argv) > 2 else 262144          # N of the profiled bench.py command
+write_traffic = (sys.argv[3] if len(sys.argv) > 3 else "traffic") == "traffic"   # "notraffic": leave profiles/hbm_traffic.json alone
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 
@@ -65,7 +66,7 @@ for k, d in summary.items():
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps({"counters": summary, "derived": derived, "dispatch": meta}, indent=1) + "\n")
 print("pmc summary ->", out / f"{tag}_pmc_summary.json")
 # the dominant force kernel of the run: the symmetric kernel when it ran, else the one-sided tiled kernel
-force_keys = [k for k in derived if "force_sym_f32" in k] or [k for k in derived if "force_tiled_f32" in k]
+force_keys = ([k for k in derived if "force_sym_f32" in k] or [k for k in derived if "force_tiled_f32" in k]) if write_traffic else []
 for k, x in derived.items():
     if k in force_keys[:1] and "hbm_read_bytes_corrected" in x and "hbm_write_bytes" in x:
         t = {"round": tag, "kernel": k, "n": n_run, "valu_busy": x.get("valu_busy_frac"), "l2_hit_rate": x.get("l2_hit_rate"),
