@@ -250,6 +250,25 @@ def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt):
     assert drift_sym < 1e-6 * np.abs(m * res["sym"]).sum(0).max()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_massless_tracers_feel_but_do_not_exert_force(nbo, precision):
+    """Half of the bodies have mass 0 (the reference's extras fixture uses such tracers): they are accelerated like
+    any other body and contribute nothing — in the symmetric kernel too, where their pair is evaluated once for both."""
+    n = 20000
+    ic = nb.plummer_2d(n, 13)
+    ic["mass"][::2] = 0.0
+    with nb.Simulation(ic, eps=0.02, precision=precision) as sim:
+        assert "symmetric=1" in sim.describe() and "uniform_mass=0" in sim.describe()
+        acc = sim.accelerations().astype(np.float64)
+    ax, ay = nbo.accel_f64(nbo.state_from_bodies(ic, np.float64), f32(0.02))
+    ref = np.stack([ax, ay], 1)
+    assert np.max(np.abs(acc - ref)) < (2e-5 if precision == "fp32" else 2e-7) * np.max(np.abs(ref))
+    heavy = ic.copy()[1::2]                                   # the same system without the tracers: same force on the heavy bodies
+    with nb.Simulation(np.ascontiguousarray(heavy), eps=0.02, precision=precision, symmetry=False) as sim:
+        acc_h = sim.accelerations().astype(np.float64)
+    assert np.max(np.abs(acc[1::2] - acc_h)) < 2e-5 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("masses", ["uniform", "individual"])
 def test_symmetric_fp64_kernel_matches_fp64_direct(nbo, masses):
     n = 20000
