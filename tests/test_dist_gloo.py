@@ -223,3 +223,59 @@ def test_two_rank_gloo_startup_agreement_logic(tmp_path):
     assert r0["tune"][0] == "allgather" and abs(r0["tune"][1]["symmetric"] - 1.6e-3) < 1e-12
     assert r0["tie"][0] == "symmetric"
     assert r0["only_ag"][0] == "allgather"
+
+
+def _allreduce_worker(rank, world, port, n, steps, out_dir):
+    """The replicated protocol's data flow on CPU: this rank's share of the unordered pairs (product planner) evaluated in
+    numpy fp64 -> partial acceleration of ALL particles, dist.all_reduce in place, every rank kicks and drifts all n."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd import _lib as L
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        items, info = L.sym_plan(n, 256, rank, world)
+        ic = nb.plummer_2d(n, 11)
+        m = ic["mass"].astype(np.float64)
+        eps2, dt = 0.05 ** 2, 1e-3
+        x = ic["pos"].astype(np.float64).copy()
+        v = ic["vel"].astype(np.float64).copy()
+        for _ in range(steps):
+            acc = np.zeros((n, 2))
+            for it in items:
+                tile, c0, c, diag = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"])
+                S = slice(tile * 2048, min((tile + 1) * 2048, n))
+                T = slice(c0 * 64, min((c0 + c) * 64, n))
+                d = x[None, T, :] - x[S, None, :]
+                inv3 = (d[..., 0] ** 2 + d[..., 1] ** 2 + eps2) ** -1.5
+                acc[S] += np.einsum("ij,ijk->ik", inv3 * m[None, T], d)
+                if not diag:
+                    acc[T] -= np.einsum("ij,ijk->jk", inv3 * m[S, None], d)
+            t = torch.from_numpy(acc)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)           # in place; the same bits on every rank
+            v += t.numpy() * dt
+            x += v * dt
+        np.save(Path(out_dir) / f"arx_rank{rank}.npy", x)
+        np.save(Path(out_dir) / f"arv_rank{rank}.npy", v)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_protocol_replicas_are_identical_and_match_unsharded(tmp_path, nbo):
+    import torch.multiprocessing as mp
+
+    import nbodysim_amd as nb
+    n, world, steps = 8192, 2, 2
+    mp.spawn(_allreduce_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    st = nbo.step_f64(nbo.state_from_bodies(nb.plummer_2d(n, 11), np.float64), 0.05, 1e-3, steps)
+    want_pos, want_vel = np.stack([st["x"], st["y"]], 1), np.stack([st["vx"], st["vy"]], 1)
+    xs = [np.load(tmp_path / f"arx_rank{r}.npy") for r in range(world)]
+    vs = [np.load(tmp_path / f"arv_rank{r}.npy") for r in range(world)]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(vs[0], vs[1])          # replicas: bit-identical
+    assert np.max(np.abs(xs[0] - want_pos)) < 1e-12 * np.max(np.abs(want_pos))
+    assert np.max(np.abs(vs[0] - want_vel)) < 1e-11 * np.max(np.abs(want_vel))
