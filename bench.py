@@ -253,6 +253,7 @@ def main() -> None:
         dist.all_gather_into_tensor(scratch, scratch[rank * 64:(rank + 1) * 64])
         if args.backend == "nccl":
             dist.reduce_scatter_tensor(scratch[:64].clone(), scratch, op=dist.ReduceOp.SUM)
+        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank,
                                     protocol=args.protocol, tune_dt=DT, uniform_mass=not args.general_mass)
