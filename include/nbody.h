@@ -145,6 +145,8 @@ typedef struct nb_params {
     float    sym_tail[3];         /* guided-tail thresholds (fractions of a launch's work from which items are cut
                                      into L/2, L/4, L/8 chunks); all 0 = 0.85, 0.94, 0.98 */
     int32_t  reserved1;
+    uint64_t first_frame;         /* value nb_frame() starts from: 0 for a new run, the dump header's frame for a restart
+                                     (the reference's Simulation::frame, Simulation.hpp:53, starts at 0: :60) */
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */

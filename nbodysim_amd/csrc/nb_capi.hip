@@ -481,6 +481,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     nb_sim *s = new (std::nothrow) nb_sim;
     if (!s) { nb_fail(NB_ENOMEM, "nb_create: out of host memory"); return nullptr; }
     s->p = p; s->n = n; s->i_begin = (size_t)p.i_begin; s->i_count = (size_t)p.i_count; s->dev = dev;
+    s->frame = p.first_frame;
     s->fp64 = p.precision == NB_FP64;
     s->rsz = s->fp64 ? 8 : 4;
     s->dims3 = p.dims == 3;

@@ -67,6 +67,7 @@ int main(int argc, char **argv)
             CHECK(nb_read_header(load, &n, &frame0, &fp));     /* validates n against the file length */
             p.eps = fp.eps; p.dt = fp.dt; p.precision = fp.precision; p.rsqrt_mode = fp.rsqrt_mode;
             p.sum_order = fp.sum_order; p.integrator = fp.integrator; p.extras = fp.extras; p.dims = fp.dims;
+            p.first_frame = frame0;                             /* the frame counter continues where the dump left off */
         }
         else if (!strcmp(argv[i], "-no-symmetry")) p.flags |= NB_FLAG_NO_SYMMETRY;
         else if (!strcmp(argv[i], "-allreduce")) p.flags |= NB_FLAG_SHARD_ALLREDUCE;

@@ -60,6 +60,7 @@ class Simulation:
         lanes_p: int = 0,
         sym_tail: Optional[tuple] = None,
         shard_allreduce: bool = False,
+        first_frame: int = 0,
     ):
         """The last eight arguments are ``nb_params.flags`` and the launch-geometry tuning fields
         (0 / True = the library's automatic choice); the library reads no environment variables."""
@@ -91,6 +92,7 @@ class Simulation:
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail
+        p.first_frame = first_frame
         p.shard_rank, p.shard_world = shard_rank, shard_world
         if acc_buffers is not None:
             p.acc_buffers[0], p.acc_buffers[1] = acc_buffers

@@ -139,8 +139,9 @@ def test_c_driver_restart_applies_the_dump_header(tmp_path):
     run(*common, "-s", "1", "-dump", str(b))                     # frame 3
     out = run("-load", str(b), "-s", "3", "-dump", str(c))       # header supplies eps, dt, quake, sequential; 2 + 3 more steps
     assert "eps 0.07, dt 0.002, fp32, quake, sequential" in out and "rsqrt=quake sum=sequential" in out
-    ba, _, pa = nb.read_bodies(a)
-    bc, _, pc = nb.read_bodies(c)
+    ba, fa, pa = nb.read_bodies(a)
+    bc, fc, pc = nb.read_bodies(c)
+    assert fa == fc == 8                                         # nb_params.first_frame: the counter continues across the restart
     assert pc.rsqrt_mode == L.NB_RSQRT_QUAKE and pc.sum_order == L.NB_SUM_SEQUENTIAL and abs(pc.dt - 0.002) < 1e-9
     for f in ("pos", "vel"):
         assert np.array_equal(ba[f].view(np.uint32), bc[f].view(np.uint32)), f
