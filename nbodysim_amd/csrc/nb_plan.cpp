@@ -78,7 +78,10 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     }
     // workgroups wanted (profiles/r01_*sweep.log): with the guided tail 24 per CU run as fast as 32 (L = 43-48 vs 33
     // at N = 262 144) and write a quarter fewer slab rows
-    const uint32_t target = (world > 1 ? 16u : 24u) * cus;
+    // (a sharded rank of the reduce-scatter protocol runs its local and its cross items as two launches with a tail
+    // each: 24 per CU there too — profiles/r02_shard_L_sweep.log: -2.5 % at 4 ranks, neutral at 8; the single launch of
+    // a replicated rank is best at 16)
+    const uint32_t target = (tune.wg_per_cu ? tune.wg_per_cu : (world > 1 ? 16u : 24u)) * cus;
     // Chunks per item.  Large systems: as many items as fill the chip `target` workgroups deep.  Small ones
     // (fewer chunk-units than that): one chunk per item would be the finest grain, but every item costs a
     // 16-KiB slab row that sym_gather re-reads and a prologue, while coarse items cost tail — the optimum

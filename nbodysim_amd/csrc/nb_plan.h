@@ -38,6 +38,7 @@ static_assert(sizeof(SymCov) == 16, "SymCov is read by the kernels as 16 bytes")
 
 struct SymTuning {
     uint32_t forced_L = 0;        // chunks per item; 0 = automatic
+    uint32_t wg_per_cu = 0;       // workgroups per CU the automatic choice aims at; 0 = 24 (one launch per step) / 16
     uint32_t late_units = 0;      // chunk-units of local work held back for the side stream (sharded ranks)
     uint32_t late_chunks = 2;     // chunks per late item
     bool guided_tail = true;      // finer items at the end of each launch
