@@ -109,7 +109,7 @@ class DeviceSampler:
             for pw, fq, _ in self.files:
                 w = self._read(pw)
                 if w is not None and (best is None or w > best[0]):
-                    best = (w, self._read(fq))
+                    best = (w, self._read(fq), self._read(pw.replace("power1_input", "temp2_input")))
             if best:
                 self.samples.append(best)
             self._stop.wait(self.period)
@@ -127,8 +127,10 @@ class DeviceSampler:
         pw = [s[0] * 1e-6 for s in self.samples]
         fq = [s[1] * 1e-6 for s in self.samples if s[1]]
         cap = max((self._read(c) or 0.0) for _, _, c in self.files) * 1e-6
+        tj = [s[2] * 1e-3 for s in self.samples if len(s) > 2 and s[2]]
         return {"samples": len(pw), "power_w_mean": sum(pw) / len(pw), "power_w_max": max(pw), "power_cap_w": cap or None,
                 "sclk_mhz_mean": (sum(fq) / len(fq)) if fq else None, "sclk_mhz_min": min(fq) if fq else None,
+                "junction_temp_c_max": max(tj) if tj else None,
                 "source": "amdgpu hwmon power1_input / freq1_input sampled during the timed region (rank 0's view; busiest visible card)"}
 
 
