@@ -54,7 +54,9 @@ PROTOCOLS = ("auto", "symmetric", "allgather", "allreduce", "tune")
 
 @dataclass(frozen=True)
 class ShardPlan:
-    """Contiguous, equal blocks of the particle index range (n % world == 0)."""
+    """Contiguous blocks of ``stride = ceil(n / world)`` particles; the last block is shorter when world does not
+    divide n (ragged).  Collectives always move ``stride`` rows per rank (one all-gather, equal counts): the replicas
+    are allocated with ``padded_n = world * stride`` rows and the rows past n are never read by the kernels."""
 
     n: int
     world: int
@@ -63,25 +65,35 @@ class ShardPlan:
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
             raise ValueError(f"bad rank/world {self.rank}/{self.world}")
-        if self.n % self.world != 0:
-            raise ValueError(f"n={self.n} must be a multiple of the world size {self.world} "
-                             "(equal blocks keep the all-gather a single collective)")
+        if self.stride * (self.world - 1) >= self.n:
+            raise ValueError(f"n={self.n} is too small for {self.world} ranks: every rank must own at least one particle")
 
     @property
-    def i_count(self) -> int:
-        return self.n // self.world
+    def stride(self) -> int:
+        return -(-self.n // self.world)
+
+    @property
+    def padded_n(self) -> int:
+        return self.stride * self.world
+
+    @property
+    def ragged(self) -> bool:
+        return self.padded_n != self.n
 
     @property
     def i_begin(self) -> int:
-        return self.rank * self.i_count
+        return self.rank * self.stride
+
+    @property
+    def i_count(self) -> int:
+        return min(self.stride, self.n - self.i_begin)
 
     @property
     def i_end(self) -> int:
         return self.i_begin + self.i_count
 
     def block(self, rank: int) -> slice:
-        c = self.n // self.world
-        return slice(rank * c, (rank + 1) * c)
+        return slice(rank * self.stride, min((rank + 1) * self.stride, self.n))
 
 
 def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False):
@@ -91,7 +103,9 @@ def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False
 
     if plan.world == 1:
         return None
-    own = full[plan.i_begin : plan.i_end]
+    if full.shape[0] != plan.padded_n:
+        raise ValueError(f"the replica must hold padded_n = {plan.padded_n} rows (n = {plan.n}, {plan.world} ranks), not {full.shape[0]}")
+    own = full[plan.i_begin : plan.i_begin + plan.stride]     # equal counts; a ragged last block sends its padding rows too
     return dist.all_gather_into_tensor(full, own, group=group, async_op=async_op)
 
 
@@ -223,7 +237,7 @@ class DistributedSimulation:
         self.sim = None
         try:
             # full-n position replicas owned by torch so the collective can write them
-            self.pos = [torch.empty((self.plan.n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
+            self.pos = [torch.zeros((self.plan.padded_n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
             # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
             self.acc_full = self.acc_owned = None
             acc_ptrs = None

@@ -71,8 +71,7 @@ def test_shard_plan():
     p = [ShardPlan(1024, 4, r) for r in range(4)]
     assert [q.i_begin for q in p] == [0, 256, 512, 768] and all(q.i_count == 256 for q in p)
     assert p[3].i_end == 1024 and p[1].block(2) == slice(512, 768)
-    with pytest.raises(ValueError):
-        ShardPlan(1000, 3, 0)
+    assert ShardPlan(1000, 3, 2).i_count == 332 and ShardPlan(1000, 3, 0).padded_n == 1002      # ragged: a shorter last block
     with pytest.raises(ValueError):
         ShardPlan(1024, 4, 4)
     assert ShardPlan(7, 1, 0).i_count == 7
@@ -279,3 +278,19 @@ def test_two_rank_gloo_allreduce_protocol_replicas_are_identical_and_match_unsha
     assert np.array_equal(xs[0], xs[1]) and np.array_equal(vs[0], vs[1])          # replicas: bit-identical
     assert np.max(np.abs(xs[0] - want_pos)) < 1e-12 * np.max(np.abs(want_pos))
     assert np.max(np.abs(vs[0] - want_vel)) < 1e-11 * np.max(np.abs(want_vel))
+
+
+def test_shard_plan_blocks_cover_the_range_also_when_ragged():
+    """ShardPlan: ceil(n / world) particles per rank, a shorter last block, equal collective counts over a padded replica."""
+    from nbodysim_amd.dist import ShardPlan
+    for n, world in ((262144, 8), (10007, 3), (20001, 2), (25000, 7), (15, 8)):
+        plans = [ShardPlan(n, world, r) for r in range(world)]
+        assert plans[0].i_begin == 0 and plans[-1].i_end == n
+        assert all(a.i_end == b.i_begin for a, b in zip(plans, plans[1:]))
+        assert all(1 <= p.i_count <= p.stride for p in plans) and sum(p.i_count for p in plans) == n
+        assert plans[0].padded_n == world * plans[0].stride >= n and plans[0].ragged == (n % world != 0)
+        assert [p.block(r) for p in plans[:1] for r in range(world)] == [slice(q.i_begin, q.i_end) for q in plans]
+    with pytest.raises(ValueError):
+        ShardPlan(7, 8, 0)                      # some rank would own nothing
+    with pytest.raises(ValueError):
+        ShardPlan(100, 4, 4)

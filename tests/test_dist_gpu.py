@@ -77,7 +77,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("world,backend,precision,n,expect_sym", [
     (1, "nccl", "fp32", 4096, 0), (2, "gloo", "fp32", 4096, 0), (4, "gloo", "fp32", 4096, 0), (2, "gloo", "fp64", 4096, 0),
-    (2, "gloo", "fp32", 32768, 1), (4, "gloo", "fp32", 32768, 1), (1, "nccl", "fp32", 32768, 0), (2, "gloo", "fp64", 32768, 1)])
+    (2, "gloo", "fp32", 32768, 1), (4, "gloo", "fp32", 32768, 1), (1, "nccl", "fp32", 32768, 0), (2, "gloo", "fp64", 32768, 1),
+    (3, "gloo", "fp32", 10007, 0), (2, "gloo", "fp64", 20001, 0)])          # ragged: the world size does not divide n
 def test_distributed_simulation_matches_single_handle(tmp_path, world, backend, precision, n, expect_sym):
     import torch.multiprocessing as mp
     steps = 6
