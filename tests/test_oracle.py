@@ -170,3 +170,35 @@ def test_extras_bit_exact_vs_real_reference_step(gold, nbo, steps):
     # the fixture really exercises both branches
     ic = gold["ic_extras_512"]
     assert (np.hypot(ic[:, 2], ic[:, 3]) > 1000).sum() > 50 and (np.hypot(ic[:, 0], ic[:, 1]) > 8e4).sum() > 100
+
+
+def test_reference_terms_summed_in_double_against_numpy(nbo):
+    """nbo.accel_f32_terms_acc64 (the reference's fp32 per-pair terms, Quadtree.hpp:136-143, accumulated in double — used
+    at N = 262 144 to separate a kernel's error from the reference's own fp32 summation noise): the same terms built
+    with numpy float32 arithmetic and summed in float64, value by value; and the reference's fp32 running sum stays
+    within its expected rounding of it."""
+    import nbodysim_amd as nb
+    n = 700
+    ic = nb.plummer_2d(n, 9)
+    ic["pos"][3] = ic["pos"][4]                                   # a coincident pair: the r_sq > 0 guard
+    st = nbo.state_from_bodies(ic)
+    eps2 = np.float32(0.05) * np.float32(0.05)
+    x, y, m = st["x"], st["y"], st["m"]
+    for mode in (nbo.RSQRT_QUAKE, nbo.RSQRT_EXACT):
+        ax, ay = nbo.accel_f32_terms_acc64(st, 0.05, mode)
+        rx = (x[None, :] - x[:, None]).astype(np.float32)
+        ry = (y[None, :] - y[:, None]).astype(np.float32)
+        r_sq = (rx * rx + ry * ry).astype(np.float32)
+        t = (r_sq + eps2).astype(np.float32)
+        if mode == nbo.RSQRT_QUAKE:
+            inv = nbo.fast_inv_sqrt(t.reshape(-1)).reshape(n, n)
+        else:
+            inv = (np.float32(1.0) / np.sqrt(t)).astype(np.float32)
+        inv3 = ((inv * inv).astype(np.float32) * inv).astype(np.float32)
+        s = (m[None, :] * inv3).astype(np.float32)
+        cx = np.where(r_sq > 0, (rx * s).astype(np.float32), np.float32(0)).astype(np.float64)
+        cy = np.where(r_sq > 0, (ry * s).astype(np.float32), np.float32(0)).astype(np.float64)
+        want_x, want_y = cx.sum(1), cy.sum(1)
+        assert np.max(np.abs(ax - want_x)) <= 1e-12 * np.max(np.abs(want_x)) and np.max(np.abs(ay - want_y)) <= 1e-12 * np.max(np.abs(want_y))
+        bx, by = nbo.accel_f32(st, 0.05, mode)
+        assert np.max(np.abs(bx - ax)) < 1e-5 * np.max(np.abs(ax))
