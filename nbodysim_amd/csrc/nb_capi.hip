@@ -73,6 +73,7 @@ struct nb_sim {
     uint32_t slabs_cap = 0;
     BodyRec *aos_dev = nullptr;     // n records (upload) / i_count records (sync)
     void *staging = nullptr;        // pinned host, i_count * 64 B
+    void *bounce = nullptr;         // pinned host bounce buffer: the library never hands pageable caller / heap memory to HIP
     double *ered_dev = nullptr;     // energy partials
     size_t ered_blocks = 0;
 
@@ -313,6 +314,47 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
     return NB_OK;
 }
 
+// Host <-> device copies of pageable memory (caller arrays, std::vector storage) go through a page-locked bounce
+// buffer owned by the handle.  Handing pageable pointers to hipMemcpy makes the runtime pin those pages itself and
+// remember the pinning; once the pages are freed and the addresses reused — e.g. by an array the caller then
+// page-locks with nb_host_register — that stale bookkeeping has aborted the process (seen once in the GPU suite,
+// inside nb_upload after nb_host_register).  With the bounce buffer the runtime only ever sees memory the library
+// or the caller explicitly page-locked.
+constexpr size_t BOUNCE_BYTES = (size_t)8 << 20;
+
+static bool is_pinned_host(const void *p);
+
+static int copy_h2d(nb_sim *s, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return NB_OK;
+    if (is_pinned_host(src)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return NB_OK;
+    }
+    if (!s->bounce) HIPCHK(hipHostMalloc(&s->bounce, BOUNCE_BYTES, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t c = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+        memcpy(s->bounce, (const char *)src + off, c);
+        HIPCHK(hipMemcpyAsync((char *)dst + off, s->bounce, c, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));                 // one bounce buffer: reuse only after the DMA
+    }
+    return NB_OK;
+}
+
+static int copy_d2h(nb_sim *s, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return NB_OK;
+    if (!s->bounce) HIPCHK(hipHostMalloc(&s->bounce, BOUNCE_BYTES, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t c = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+        HIPCHK(hipMemcpyAsync(s->bounce, (const char *)src + off, c, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        memcpy((char *)dst + off, s->bounce, c);
+    }
+    return NB_OK;
+}
+
 static int plan_sym(nb_sim *s)
 {
     const uint32_t n = (uint32_t)s->n;
@@ -341,10 +383,11 @@ static int plan_sym(nb_sim *s)
     HIPCHK(hipMalloc((void **)&s->sym_cov_dev, (cov.size() ? cov.size() : 1) * sizeof(SymCov)));
     HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
     HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(pl.slab_r_elems ? pl.slab_r_elems : 1) * s->esz));
-    HIPCHK(hipMemcpy(s->sym_items_dev, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_rowbase_dev, bounds.data(), bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->sym_cov_begin_dev, cbegin.data(), cbegin.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!cov.empty()) HIPCHK(hipMemcpy(s->sym_cov_dev, cov.data(), cov.size() * sizeof(SymCov), hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = copy_h2d(s, s->sym_items_dev, pl.items.data(), pl.items.size() * sizeof(SymItem)))) return rc;
+    if ((rc = copy_h2d(s, s->sym_rowbase_dev, bounds.data(), bounds.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = copy_h2d(s, s->sym_cov_begin_dev, cbegin.data(), cbegin.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = copy_h2d(s, s->sym_cov_dev, cov.data(), cov.size() * sizeof(SymCov)))) return rc;
     // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
     // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
     // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
@@ -384,6 +427,7 @@ static void free_all(nb_sim *s)
     if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
     if (s->staging) (void)hipHostFree(s->staging);
+    if (s->bounce) (void)hipHostFree(s->bounce);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
@@ -400,7 +444,7 @@ static int do_upload(nb_sim *s, const nb_body *in)
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
-    HIPCHK(hipMemcpyAsync(s->aos_dev, in, s->n * sizeof(nb_body), hipMemcpyHostToDevice, s->stream));
+    { const int rc = copy_h2d(s, s->aos_dev, in, s->n * sizeof(nb_body)); if (rc) return rc; }
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
     for (int b = 0; b < 2; ++b) {
@@ -1215,8 +1259,7 @@ extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
                                                            s->ered_dev, s->ered_dev + g);
     HIPCHK(hipGetLastError());
     std::vector<double> h(2 * (size_t)g);
-    HIPCHK(hipMemcpyAsync(h.data(), s->ered_dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    { const int rc = copy_d2h(s, h.data(), s->ered_dev, h.size() * sizeof(double)); if (rc) return rc; }
     double K = 0.0, U = 0.0;
     for (uint32_t b = 0; b < g; ++b) { K += h[b]; U += h[g + b]; }
     *kinetic = K;
