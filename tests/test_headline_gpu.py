@@ -259,3 +259,21 @@ def test_replicated_allreduce_protocol_in_process(precision, parts):
     tol = (2e-6, 2e-5) if precision == "fp32" else (2e-7, 2e-7)
     assert max_rel(outs[0]["pos"], whole["pos"]) < tol[0] and max_rel(outs[0]["vel"], whole["vel"]) < tol[1]
     assert all(abs(e - e_whole) < (1e-5 if precision == "fp32" else 1e-10) * abs(e_whole) for e in energies)
+
+
+def test_config2_lds_tiled_kernel_at_65536_vs_fp64_direct(nbo):
+    """BASELINE config 2 as written: N = 65 536 fp32 direct O(N^2) on one MI355X with the LDS tile = 256 kernel
+    (`force_tiled_f32`, north_star's design; the symmetric kernel is switched off), 2 steps against FP64-DIRECT, and the
+    symmetric kernel on the same data beside it."""
+    n = 65536
+    ic = nb.plummer_2d(n, 42)
+    d = nbo.step_f64(nbo.state_from_bodies(ic, np.float64), f32(EPS), f32(DT), 2)
+    pos64, vel64 = np.stack([d["x"], d["y"]], 1), np.stack([d["vx"], d["vy"]], 1)
+    acc64 = np.stack([d["ax"], d["ay"]], 1)                     # a(x_1): the last force evaluation
+    for symm in (False, True):
+        with nb.Simulation(ic, eps=EPS, symmetry=symm) as sim:
+            assert f"symmetric={int(symm)}" in sim.describe() and "tile_j=256" in sim.describe()
+            sim.advance(2, DT)
+            got = sim.sync()
+        assert max_rel(got["pos"], pos64) < 1e-5 and max_rel(got["vel"], vel64) < 1e-5, symm
+        assert np.max(np.abs(got["acc"].astype(np.float64) - acc64)) < 2e-5 * np.max(np.abs(acc64)), symm
