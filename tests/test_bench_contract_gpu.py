@@ -62,3 +62,28 @@ def test_bench_fp64_and_3d_variants_run():
     d = run_bench("--n", "16384", "--steps", "2", "--warmup", "1", "--no-symmetry", "--no-cpu-baseline")
     assert d["roofline"]["kernel"] == "force_tiled_f32" and "LDS tiles of 256" in d["config"]["workload"]
     assert abs(d["roofline"]["executed_frac"] / d["roofline"]["frac"] - 13.0 / 14.0) < 1e-6
+
+
+def test_bench_line_of_a_two_rank_rehearsal():
+    """The N > 1 path of bench.py end to end, as the driver launches it (torch.distributed.run, one process per rank),
+    rehearsed with two ranks over gloo on this one GPU (RCCL refuses two ranks per device): the autotune's verdict,
+    the per-phase report and the contract fields are all there.  Not a scaling measurement."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--n", "32768", "--steps", "4", "--warmup", "1",
+                        "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and "cpu_baseline" not in d
+    assert d["config"]["protocol"] in ("symmetric", "allreduce", "allgather") and d["config"]["backend"] == "gloo"
+    t = d["config"]["protocol_tuning"]
+    assert t["chosen"].startswith(d["config"]["protocol"]) and set(t["ms_per_step"]) == {"symmetric", "symmetric+late", "allreduce", "allgather"}
+    ph = d["phases_ms"]
+    assert ph["rank0"]["steps"] == 4 and ph["max_over_ranks"]["stream_total"] > 0
+    assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["energy"]["rel_drift"]) < 1e-3
