@@ -198,7 +198,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # 0.37 s at one GPU, ~50 ms at eight: enough steps to average over
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=N_DEFAULT)
+    ap.add_argument("--n", "--nbodies", dest="n", type=int, default=N_DEFAULT,
+                    help="number of bodies (use --nbodies under torch.distributed.run, whose own parser finds --n ambiguous)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--rsqrt", default="exact", choices=["exact", "quake"])
     ap.add_argument("--dims", type=int, default=2, choices=[2, 3], help="3 = the 3-D build extension (not the headline config)")

@@ -73,7 +73,7 @@ def test_bench_line_of_a_two_rank_rehearsal():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--n", "32768", "--steps", "4", "--warmup", "1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--nbodies", "32768", "--steps", "4", "--warmup", "1",
                         "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
