@@ -349,6 +349,11 @@ int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out);
 int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
                       nb_sym_item *items_out, size_t cap, nb_sym_info *info);
 
+/* Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) exactly as the device kernels evaluate it, on an array of n (even)
+ * floats: y_scalar through the scalar form (reference-order kernel), y_packed through the packed form (tiled and
+ * symmetric kernels).  Test hook for the bit-exact check against the reference's golden grid. */
+int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_packed, size_t n);
+
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);
 

@@ -168,6 +168,7 @@ PROTOTYPES = {
     "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(nb_params), C.c_void_p, C.c_size_t, C.POINTER(nb_sym_info)]),
     "nb_sym_plan_info": (C.c_int, [C.c_void_p, C.POINTER(nb_sym_info)]),
     "nb_last_error_code": (C.c_int, []),
+    "nb_debug_fast_inv_sqrt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),

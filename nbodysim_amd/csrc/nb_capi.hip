@@ -1414,6 +1414,36 @@ extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *forc
     return NB_OK;
 }
 
+// Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) as the device evaluates it, on an array: y_scalar from the scalar form
+// used by the sequential kernel, y_packed from the packed form of the tiled / symmetric kernels.  n must be even.
+extern "C" int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_packed, size_t n)
+{
+    if (!x || !y_scalar || !y_packed || n == 0 || (n & 1) || n > 0x7fffff00u) return nb_fail(NB_EINVAL, "nb_debug_fast_inv_sqrt: bad arguments (n even)");
+    if (nb_device_count() <= 0) return nb_fail(NB_ENODEVICE, "nb_debug_fast_inv_sqrt: no HIP device visible");
+    float *dx = nullptr, *ds = nullptr, *dp = nullptr, *host = nullptr;
+    int rc = NB_OK;
+    hipError_t e;
+    // page-locked staging: pageable caller memory is never handed to HIP (see copy_h2d)
+    if ((e = hipHostMalloc((void **)&host, 3 * n * sizeof(float), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void **)&dx, n * sizeof(float))) != hipSuccess || (e = hipMalloc((void **)&ds, n * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc((void **)&dp, n * sizeof(float))) != hipSuccess) {
+        rc = nb_fail(hip_code(e), "nb_debug_fast_inv_sqrt: allocation: %s", hipGetErrorString(e));
+    } else {
+        memcpy(host, x, n * sizeof(float));
+        if ((e = hipMemcpy(dx, host, n * sizeof(float), hipMemcpyHostToDevice)) == hipSuccess) {
+            quake_rsqrt_array<<<(unsigned)((n + BLOCK - 1) / BLOCK), BLOCK>>>(dx, ds, dp, (uint32_t)n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(host + n, ds, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(host + 2 * n, dp, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = nb_fail(hip_code(e), "nb_debug_fast_inv_sqrt: %s", hipGetErrorString(e));
+        else { memcpy(y_scalar, host + n, n * sizeof(float)); memcpy(y_packed, host + 2 * n, n * sizeof(float)); }
+    }
+    (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dp);
+    if (host) (void)hipHostFree(host);
+    return rc;
+}
+
 extern "C" int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out)
 {
     if (!s || !out) return nb_fail(NB_EINVAL, "nb_sym_plan_info: NULL argument");

@@ -161,6 +161,12 @@ __device__ __forceinline__ float quake_rsqrt(float number)
     return y * (1.5f - (number * 0.5f * y * y));
 }
 
+// fast_inv_sqrt on an array: both device forms (scalar as in force_seq_f32, packed as in the tiled / symmetric
+// kernels) — for the bit-exact check against the reference's golden grid (nb_debug_fast_inv_sqrt).
+__device__ __forceinline__ v2f quake_rsqrt2(v2f t);
+__global__ __launch_bounds__(BLOCK)
+void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar, float *__restrict__ y_packed, uint32_t n);
+
 __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 {
 #pragma clang fp contract(off)
@@ -169,6 +175,17 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
     const v2f half = {0.5f, 0.5f}, c15 = {1.5f, 1.5f};
     return y * (c15 - (t * half * y * y));
 }
+
+__global__ __launch_bounds__(BLOCK)
+void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar, float *__restrict__ y_packed, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    y_scalar[i] = quake_rsqrt(x[i]);
+    const v2f p = quake_rsqrt2((v2f){x[i], x[i ^ 1u] });       // the neighbour rides in the other half (n is even or i^1 < n is checked by the host)
+    y_packed[i] = p.x;
+}
+
 
 // ---------------------------------------------------------------------------
 // force_tiled_f32 — the fast path.

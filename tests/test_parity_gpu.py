@@ -62,6 +62,17 @@ def test_sequential_quake_bit_exact_vs_reference_golden(gold, steps):
     assert np.array_equal(bits(got), bits(want))
 
 
+def test_device_fast_inv_sqrt_bit_exact_on_the_reference_golden_grid(gold):
+    """Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111): the device's scalar and packed forms against the 4096-point
+    grid evaluated by the compiled reference (tests/golden/fast_inv_sqrt_{x,y}.npy), bit for bit."""
+    import ctypes as C
+    x = np.ascontiguousarray(gold["fast_inv_sqrt_x"], np.float32)
+    want = np.ascontiguousarray(gold["fast_inv_sqrt_y"], np.float32)
+    ys, yp = np.empty_like(x), np.empty_like(x)
+    L.check("nb_debug_fast_inv_sqrt", nb.load().nb_debug_fast_inv_sqrt(x.ctypes.data, ys.ctypes.data, yp.ctypes.data, x.size))
+    assert x.size == 4096 and np.array_equal(bits(ys), bits(want)) and np.array_equal(bits(yp), bits(want))
+
+
 @pytest.mark.parametrize("name,n,eps", [("ref_direct_acc_1024", 1024, EPS), ("ref_direct_acc_4096", 4096, EPS),
                                         ("ref_direct_acc_eps1_1024", 1024, 1.0)])
 def test_sequential_quake_accelerations_bit_exact(gold, name, n, eps):
