@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 3
 
 /* ---- particle record -------------------------------------------------------
  * Bit-compatible with the reference's `struct alignas(16) Body`
@@ -181,11 +181,21 @@ int nb_wait(nb_sim *s);
  * main.cpp:623-627. */
 int nb_sync(nb_sim *s, nb_body *out);
 
-/* Page-lock a host array (e.g. the storage of `std::vector<Body> bodies`) so that nb_sync
- * DMAs straight into it instead of going through the library's staging buffer + memcpy
- * (16.8 MB per sync at N = 262 144).  Unregister before the array is freed or reallocated. */
-int nb_host_register(void *ptr, size_t bytes);
-int nb_host_unregister(void *ptr);
+/* Host memory the copy engine may read / write DIRECTLY (nb_sync, nb_snapshot_begin, nb_sync_positions, nb_create,
+ * nb_upload): only ranges this library knows to be page-locked over the WHOLE transfer — blocks from nb_host_alloc and
+ * ranges registered here.  Any other pointer (malloc'ed arrays, `std::vector<Body>` storage — what the reference's
+ * caller holds, main.cpp:623-627 — numpy arrays) is always legal and moves through the handle's page-locked staging
+ * buffer in pipelined pieces (the host copy of piece k overlaps the DMA of piece k + 1).
+ *
+ * nb_host_register page-locks [ptr, ptr + bytes) in place.  ptr must be page-aligned and bytes a whole number of
+ * pages (sysconf(_SC_PAGESIZE)); anything else is refused with NB_EINVAL: a registration pins whole pages, and the
+ * first / last page of an unaligned heap array also holds its neighbours' data, which is not the caller's to pin.
+ * Unregister (by the same ptr) BEFORE the storage is released; never register storage that may be reallocated
+ * behind your back (a std::vector's).  nb_host_alloc / nb_host_free hand out page-locked blocks owned by the library. */
+int   nb_host_register(void *ptr, size_t bytes);
+int   nb_host_unregister(void *ptr);
+void *nb_host_alloc(size_t bytes);
+int   nb_host_free(void *ptr);
 
 /* Positions only (8 bytes/body instead of 64): the fast path for a viewer that
  * only draws (main.cpp:623-627 consumer).  out holds 2*i_count floats (x,y) — 3*i_count
@@ -196,8 +206,10 @@ int nb_sync_positions(nb_sim *s, float *out_xy);
  * copy one step late: nb_snapshot_begin packs the owned block as of the work enqueued so far and starts its D2H
  * copy on a separate copy stream, then returns; steps enqueued afterwards run concurrently with the transfer
  * (16.8 MB per frame at N = 262 144).  nb_snapshot_wait blocks until `out` is complete.  One snapshot in flight
- * per handle; `out` should be page-locked (nb_host_register) — otherwise the data lands in the library's staging
- * buffer and is copied to `out` inside nb_snapshot_wait.  nb_sync stays the simple blocking form. */
+ * per handle.  If `out` is page-locked memory known to the library (nb_host_alloc / nb_host_register) the copy engine
+ * writes it directly; otherwise the data lands in the library's staging buffer and is copied to `out` inside
+ * nb_snapshot_wait — which a caller issues after enqueueing the next step, so that host copy overlaps the GPU too.
+ * nb_sync stays the simple blocking form. */
 int nb_snapshot_begin(nb_sim *s, nb_body *out);
 int nb_snapshot_wait(nb_sim *s);
 
@@ -217,6 +229,12 @@ int nb_accelerations(nb_sim *s);
  * (U of block B = - sum_{i in B} sum_{j > i} m_i m_j / sqrt(...): every unordered pair is
  * counted by the handle that owns its lower index), so the shares of all ranks add up to the total. */
 int nb_energy(nb_sim *s, double *kinetic, double *potential);
+
+/* Total linear momentum sum m v (the reference's Body::momentum, Body.hpp:103-106, summed) into p_xyz[3] (p_xyz[2] = 0
+ * for a 2-D handle) and, if l_z is not NULL, the angular momentum about the origin sum m (x vy - y vx); fp64
+ * accumulation on the device in a fixed order.  Both are conserved by the pairwise force (Newton's third law) up to
+ * rounding, whatever the softening; a sharded handle returns its owned block's share (the shares add up). */
+int nb_momentum(nb_sim *s, double *p_xyz, double *l_z);
 
 /* Counters: Simulation::frame (Simulation.hpp:53) and sizes. */
 uint64_t nb_frame(const nb_sim *s);

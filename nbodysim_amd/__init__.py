@@ -10,6 +10,7 @@ from ._lib import (  # noqa: F401
     BODY3_DTYPE,
     BODY_DTYPE,
     NBodyError,
+    PinnedBodies,
     bodies_array,
     load,
     default_ics,
@@ -22,6 +23,7 @@ __all__ = [
     "BODY3_DTYPE",
     "BODY_DTYPE",
     "NBodyError",
+    "PinnedBodies",
     "Simulation",
     "bodies_array",
     "load",

@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libnbody_hip.so"
 
-NB_ABI_VERSION = 2
+NB_ABI_VERSION = 3
 
 # enums (include/nbody.h)
 NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -138,9 +138,12 @@ PROTOTYPES = {
     "nb_snapshot_wait": (C.c_int, [C.c_void_p]),
     "nb_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "nb_host_unregister": (C.c_int, [C.c_void_p]),
+    "nb_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "nb_host_free": (C.c_int, [C.c_void_p]),
     "nb_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nb_accelerations": (C.c_int, [C.c_void_p]),
     "nb_energy": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nb_momentum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nb_frame": (C.c_uint64, [C.c_void_p]),
     "nb_count": (C.c_size_t, [C.c_void_p]),
     "nb_owned_begin": (C.c_size_t, [C.c_void_p]),
@@ -234,6 +237,34 @@ def bodies_array(n: int) -> np.ndarray:
     """Zero-initialised array of n 64-byte Body records (padding zero)."""
     raw = np.zeros(n * BODY_DTYPE.itemsize, dtype=np.uint8)
     return raw.view(BODY_DTYPE)
+
+
+class PinnedBodies:
+    """n Body records in page-locked memory owned by the library (``nb_host_alloc``): the destination that
+    ``nb_sync`` / ``nb_snapshot_begin`` DMA into directly.  ``.array`` is the numpy view; ``close()`` (or the
+    context manager) releases the block — the view must not be used afterwards."""
+
+    def __init__(self, n: int):
+        lib = load()
+        self.nbytes = n * BODY_DTYPE.itemsize
+        self._ptr = lib.nb_host_alloc(self.nbytes)
+        if not self._ptr:
+            raise NBodyError("nb_host_alloc", last_error_code(), last_error())
+        buf = (C.c_uint8 * self.nbytes).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=BODY_DTYPE)
+        self.array[:] = np.zeros((), BODY_DTYPE)
+
+    def close(self) -> None:
+        if self._ptr:
+            self.array = None
+            check("nb_host_free", load().nb_host_free(self._ptr))
+            self._ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def plummer_3d(n: int, seed: int = 42) -> np.ndarray:

@@ -18,8 +18,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
+
+#include <unistd.h>
 
 using namespace nbk;
 
@@ -73,8 +76,10 @@ struct nb_sim {
     uint32_t slabs_cap = 0;
     BodyRec *aos_dev = nullptr;     // n records (upload) / i_count records (sync)
     void *staging = nullptr;        // pinned host, i_count * 64 B
-    void *bounce = nullptr;         // pinned host bounce buffer: the library never hands pageable caller / heap memory to HIP
+    void *bounce = nullptr;         // pinned host bounce ring (BOUNCE_SLOTS x BOUNCE_SLOT_BYTES): pageable caller memory never reaches HIP
+    hipEvent_t ev_bounce[4] = {nullptr, nullptr, nullptr, nullptr};   // one per slot / per staged piece
     double *ered_dev = nullptr;     // energy partials
+    double *pred_dev = nullptr;     // momentum partials (nb_momentum), allocated on first use
     size_t ered_blocks = 0;
 
     // launch geometry (per job: particles per lane and j-slices)
@@ -117,6 +122,8 @@ struct nb_sim {
     hipStream_t aux = nullptr;
     bool aux_local = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_late = nullptr;
+    hipEvent_t ev_x[2] = {nullptr, nullptr};   // in-process exchanges: fences between the handles' streams
+    uint64_t peers_enabled = 0;                // devices whose memory this handle's device has mapped
 
     // profiling
     bool prof = false;
@@ -314,43 +321,119 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
     return NB_OK;
 }
 
-// Host <-> device copies of pageable memory (caller arrays, std::vector storage) go through a page-locked bounce
-// buffer owned by the handle.  Handing pageable pointers to hipMemcpy makes the runtime pin those pages itself and
-// remember the pinning; once the pages are freed and the addresses reused — e.g. by an array the caller then
-// page-locks with nb_host_register — that stale bookkeeping has aborted the process (seen once in the GPU suite,
-// inside nb_upload after nb_host_register).  With the bounce buffer the runtime only ever sees memory the library
-// or the caller explicitly page-locked.
-constexpr size_t BOUNCE_BYTES = (size_t)8 << 20;
+// ---------------------------------------------------------------------------
+// host memory
+// ---------------------------------------------------------------------------
+// The copy engine is only ever pointed at host memory this library KNOWS to be page-locked over the whole transfer:
+// its own buffers (hipHostMalloc) and the ranges in the registry below — whole pages registered through
+// nb_host_register, or blocks handed out by nb_host_alloc.  Everything else (caller arrays, std::vector storage,
+// numpy arrays) moves through the handle's page-locked bounce buffer in pipelined chunks.
+// Why so strict: hipHostRegister / the runtime's own pinning of pageable copy sources work on whole
+// PAGES; a malloc'ed array shares its first and last page with whatever the heap put next to it, and a registration
+// that outlives the array (a std::vector that reallocated) keeps pinning pages that now belong to someone else.
+// Round 2 saw one process abort inside nb_upload right after nb_host_register of an unaligned numpy array; the
+// constructions of tools/pin_probe.hip (profiles/r03_pin_probe.log) show what the runtime does in each case.
+struct PinnedRange { uintptr_t lo, hi; bool owned; };
+static std::mutex g_pin_mutex;
+static std::vector<PinnedRange> g_pinned;
 
-static bool is_pinned_host(const void *p);
+static bool pinned_covers(const void *p, size_t bytes)
+{
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (const PinnedRange &r : g_pinned)
+        if (a >= r.lo && b <= r.hi && b >= a) return true;
+    return false;
+}
 
+static size_t host_page_size()
+{
+    const long ps = sysconf(_SC_PAGESIZE);
+    return ps > 0 ? (size_t)ps : 4096;
+}
+
+constexpr size_t BOUNCE_SLOTS = 4;
+constexpr size_t BOUNCE_SLOT_BYTES = (size_t)2 << 20;       // 4 x 2 MiB: a DMA, a host memcpy and two slots of slack in flight
+constexpr size_t BOUNCE_BYTES = BOUNCE_SLOTS * BOUNCE_SLOT_BYTES;
+
+static int ensure_bounce(nb_sim *s)
+{
+    if (!s->bounce) HIPCHK(hipHostMalloc(&s->bounce, BOUNCE_BYTES, hipHostMallocDefault));
+    for (size_t k = 0; k < BOUNCE_SLOTS; ++k)
+        if (!s->ev_bounce[k]) HIPCHK(hipEventCreateWithFlags(&s->ev_bounce[k], hipEventDisableTiming));
+    return NB_OK;
+}
+
+// Host -> device on `st`; returns when the data has left `src` (the caller may free it).  Pageable sources are
+// copied slot by slot into the bounce buffer; slot k is reused only after its DMA (event) is complete, so the
+// host memcpy of chunk c + 1 overlaps the DMA of chunk c.
 static int copy_h2d(nb_sim *s, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return NB_OK;
-    if (is_pinned_host(src)) {
+    if (pinned_covers(src, bytes)) {
         HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         return NB_OK;
     }
-    if (!s->bounce) HIPCHK(hipHostMalloc(&s->bounce, BOUNCE_BYTES, hipHostMallocDefault));
-    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
-        const size_t c = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
-        memcpy(s->bounce, (const char *)src + off, c);
-        HIPCHK(hipMemcpyAsync((char *)dst + off, s->bounce, c, hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));                 // one bounce buffer: reuse only after the DMA
+    { const int rc = ensure_bounce(s); if (rc) return rc; }
+    size_t c = 0;
+    for (size_t off = 0; off < bytes; off += BOUNCE_SLOT_BYTES, ++c) {
+        const size_t k = c % BOUNCE_SLOTS, len = bytes - off < BOUNCE_SLOT_BYTES ? bytes - off : BOUNCE_SLOT_BYTES;
+        char *slot = (char *)s->bounce + k * BOUNCE_SLOT_BYTES;
+        if (c >= BOUNCE_SLOTS) HIPCHK(hipEventSynchronize(s->ev_bounce[k]));
+        memcpy(slot, (const char *)src + off, len);
+        HIPCHK(hipMemcpyAsync((char *)dst + off, slot, len, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipEventRecord(s->ev_bounce[k], s->stream));
     }
+    HIPCHK(hipStreamSynchronize(s->stream));
     return NB_OK;
 }
 
-static int copy_d2h(nb_sim *s, void *dst, const void *src, size_t bytes)
+// Device -> host on `st` (ordered after the work enqueued there), blocking.  Pageable destinations: all chunk DMAs
+// are enqueued at once into the slots of `stage` (page-locked, >= bytes, or the bounce ring when stage is NULL) and
+// the host copies chunk c out while chunk c + 1 is still in flight.
+static int copy_d2h(nb_sim *s, void *dst, const void *src, size_t bytes, hipStream_t st = nullptr, void *stage = nullptr)
 {
     if (bytes == 0) return NB_OK;
-    if (!s->bounce) HIPCHK(hipHostMalloc(&s->bounce, BOUNCE_BYTES, hipHostMallocDefault));
-    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
-        const size_t c = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
-        HIPCHK(hipMemcpyAsync(s->bounce, (const char *)src + off, c, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
-        memcpy((char *)dst + off, s->bounce, c);
+    if (!st) st = s->stream;
+    if (pinned_covers(dst, bytes)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return NB_OK;
+    }
+    { const int rc = ensure_bounce(s); if (rc) return rc; }
+    if (stage) {
+        // whole transfer staged: BOUNCE_SLOTS equal pieces, one event each
+        const size_t piece = ((bytes + BOUNCE_SLOTS - 1) / BOUNCE_SLOTS + 63) & ~(size_t)63;
+        size_t k = 0;
+        for (size_t off = 0; off < bytes; off += piece, ++k) {
+            const size_t len = bytes - off < piece ? bytes - off : piece;
+            HIPCHK(hipMemcpyAsync((char *)stage + off, (const char *)src + off, len, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(s->ev_bounce[k], st));
+        }
+        k = 0;
+        for (size_t off = 0; off < bytes; off += piece, ++k) {
+            const size_t len = bytes - off < piece ? bytes - off : piece;
+            HIPCHK(hipEventSynchronize(s->ev_bounce[k]));
+            memcpy((char *)dst + off, (const char *)stage + off, len);
+        }
+        return NB_OK;
+    }
+    size_t issued = 0, done = 0;
+    const size_t chunks = (bytes + BOUNCE_SLOT_BYTES - 1) / BOUNCE_SLOT_BYTES;
+    while (done < chunks) {
+        while (issued < chunks && issued < done + BOUNCE_SLOTS) {
+            const size_t off = issued * BOUNCE_SLOT_BYTES, len = bytes - off < BOUNCE_SLOT_BYTES ? bytes - off : BOUNCE_SLOT_BYTES;
+            const size_t k = issued % BOUNCE_SLOTS;
+            HIPCHK(hipMemcpyAsync((char *)s->bounce + k * BOUNCE_SLOT_BYTES, (const char *)src + off, len, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(s->ev_bounce[k], st));
+            ++issued;
+        }
+        const size_t off = done * BOUNCE_SLOT_BYTES, len = bytes - off < BOUNCE_SLOT_BYTES ? bytes - off : BOUNCE_SLOT_BYTES;
+        const size_t k = done % BOUNCE_SLOTS;
+        HIPCHK(hipEventSynchronize(s->ev_bounce[k]));
+        memcpy((char *)dst + off, (const char *)s->bounce + k * BOUNCE_SLOT_BYTES, len);
+        ++done;
     }
     return NB_OK;
 }
@@ -419,7 +502,7 @@ static void free_all(nb_sim *s)
     if (s->own_pos) { (void)hipFree(s->pos[0]); (void)hipFree(s->pos[1]); }
     (void)hipFree(s->mass); (void)hipFree(s->radius);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
-    (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev);
+    (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev); (void)hipFree(s->pred_dev);
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
@@ -428,10 +511,12 @@ static void free_all(nb_sim *s)
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
     if (s->staging) (void)hipHostFree(s->staging);
     if (s->bounce) (void)hipHostFree(s->bounce);
+    for (hipEvent_t e : s->ev_bounce) if (e) (void)hipEventDestroy(e);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->ev_late) (void)hipEventDestroy(s->ev_late);
+    for (hipEvent_t e : s->ev_x) if (e) (void)hipEventDestroy(e);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -911,14 +996,8 @@ static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double d
 static bool sharded(const nb_sim *s) { return s->i_count != s->n; }
 static bool two_phase(const nb_sim *s) { return sharded(s) && s->p.sum_order != NB_SUM_SEQUENTIAL && !s->sym_sharded; }
 
-extern "C" int nb_step_begin(nb_sim *s, float dt)
+static int step_begin_enqueue(nb_sim *s)
 {
-    if (!s) return nb_fail(NB_EINVAL, "nb_step_begin: NULL handle");
-    if (s->in_step) return nb_fail(NB_ESTATE, "nb_step_begin: previous step not finished");
-    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) return nb_fail(NB_EINVAL, "sharded stepping supports the kick-drift integrator only");
-    if (bind(s)) return NB_EHIP;
-    s->pending_dt = dt > 0.0f ? dt : s->p.dt;
-    s->in_step = true;
     if (s->sym_replicated) {
         // every position is already here (each rank integrates everything): all items in one launch, then this rank's
         // PARTIAL acceleration of every particle -> acc_full, which the host all-reduces before nb_step_finish
@@ -942,6 +1021,19 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
     return NB_OK;
 }
 
+extern "C" int nb_step_begin(nb_sim *s, float dt)
+{
+    if (!s) return nb_fail(NB_EINVAL, "nb_step_begin: NULL handle");
+    if (s->in_step) return nb_fail(NB_ESTATE, "nb_step_begin: previous step not finished");
+    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) return nb_fail(NB_EINVAL, "sharded stepping supports the kick-drift integrator only");
+    if (bind(s)) return NB_EHIP;
+    s->pending_dt = dt > 0.0f ? dt : s->p.dt;
+    const int rc = step_begin_enqueue(s);
+    if (rc) return rc;              // the handle is NOT left "in step": the caller sees the real error and may retry or destroy it
+    s->in_step = true;
+    return NB_OK;
+}
+
 extern "C" int nb_step_mid(nb_sim *s)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_step_mid: NULL handle");
@@ -951,7 +1043,6 @@ extern "C" int nb_step_mid(nb_sim *s)
     if (bind(s)) return NB_EHIP;
     int rc = launch_sym_items(s, s->sym_items_local, s->sym_items_cross);   // cross-block pairs: need the gathered positions
     if (rc) return rc;
-    s->mid_done = true;
     if (s->sym_items_late) {
         // the held-back local items go to the side stream once the cross items are through: they run while the
         // host's reduce-scatter of acc_full is in flight and are folded in by nb_step_finish
@@ -961,7 +1052,9 @@ extern "C" int nb_step_mid(nb_sim *s)
         HIPCHK(hipEventRecord(s->ev_late, s->aux));
     }
     if (s->aux_local) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));   // the local items' slabs
-    return launch_sym_gather(s, false, 0.0);           // partial acceleration of every particle -> acc_full
+    if ((rc = launch_sym_gather(s, false, 0.0))) return rc;                   // partial acceleration of every particle -> acc_full
+    s->mid_done = true;                                // only once everything was enqueued: a failed call can be seen and repeated
+    return NB_OK;
 }
 
 extern "C" int nb_step_finish(nb_sim *s)
@@ -1117,26 +1210,65 @@ static int ensure_staging(nb_sim *s)
     return NB_OK;
 }
 
-// Host memory made DMA-able with nb_host_register (or hipHostMalloc/hipHostRegister by the caller)
-// is written by the copy engine directly; anything else goes through the pinned staging buffer.
-static bool is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
-
+// Page-locked host memory the library may DMA into / out of directly.  Whole pages only: a registration pins every
+// page it touches, and pages shared with unrelated heap data (the first and last page of a malloc'ed array) must not be
+// pinned on behalf of one array — so an unaligned range is REFUSED, not rounded (the caller does not own the rest of
+// those pages).  Page-aligned storage comes from nb_host_alloc, posix_memalign / aligned_alloc or mmap.
 extern "C" int nb_host_register(void *ptr, size_t bytes)
 {
     if (!ptr || !bytes) return nb_fail(NB_EINVAL, "nb_host_register: NULL argument");
+    const size_t ps = host_page_size();
+    if (((uintptr_t)ptr % ps) != 0 || (bytes % ps) != 0)
+        return nb_fail(NB_EINVAL, "nb_host_register: [%p, +%zu) is not a whole number of %zu-byte pages; registration pins whole pages, "
+                                  "and the pages an unaligned array shares with its heap neighbours are not the caller's to pin "
+                                  "(use nb_host_alloc, or page-aligned storage)", ptr, bytes, ps);
+    if (pinned_covers(ptr, 1)) return nb_fail(NB_ESTATE, "nb_host_register: %p is already registered", ptr);
     HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    g_pinned.push_back(PinnedRange{(uintptr_t)ptr, (uintptr_t)ptr + bytes, false});
     return NB_OK;
 }
 
+// Only ranges registered through nb_host_register, by their start address, and before their storage is released.
 extern "C" int nb_host_unregister(void *ptr)
 {
     if (!ptr) return nb_fail(NB_EINVAL, "nb_host_unregister: NULL argument");
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        size_t k = 0;
+        while (k < g_pinned.size() && !(g_pinned[k].lo == (uintptr_t)ptr && !g_pinned[k].owned)) ++k;
+        if (k == g_pinned.size()) return nb_fail(NB_EINVAL, "nb_host_unregister: %p was not registered with nb_host_register", ptr);
+        g_pinned.erase(g_pinned.begin() + (long)k);
+    }
     HIPCHK(hipHostUnregister(ptr));
+    return NB_OK;
+}
+
+// Page-locked, page-aligned host memory owned by the library (hipHostMalloc): the simplest destination for
+// nb_sync / nb_snapshot_begin that the copy engine writes directly.  NULL on failure (nb_last_error).
+extern "C" void *nb_host_alloc(size_t bytes)
+{
+    if (!bytes) { nb_fail(NB_EINVAL, "nb_host_alloc: zero bytes"); return nullptr; }
+    if (nb_device_count() <= 0) { nb_fail(NB_ENODEVICE, "nb_host_alloc: no HIP device visible"); return nullptr; }
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); nb_fail(hip_code(e), "nb_host_alloc: hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    g_pinned.push_back(PinnedRange{(uintptr_t)p, (uintptr_t)p + bytes, true});
+    return p;
+}
+
+extern "C" int nb_host_free(void *ptr)
+{
+    if (!ptr) return NB_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        size_t k = 0;
+        while (k < g_pinned.size() && !(g_pinned[k].lo == (uintptr_t)ptr && g_pinned[k].owned)) ++k;
+        if (k == g_pinned.size()) return nb_fail(NB_EINVAL, "nb_host_free: %p did not come from nb_host_alloc", ptr);
+        g_pinned.erase(g_pinned.begin() + (long)k);
+    }
+    HIPCHK(hipHostFree(ptr));
     return NB_OK;
 }
 
@@ -1183,7 +1315,7 @@ extern "C" int nb_snapshot_begin(nb_sim *s, nb_body *out)
         HIPCHK(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
     }
-    s->snap_direct = is_pinned_host(out);
+    s->snap_direct = pinned_covers(out, s->i_count * sizeof(nb_body));
     if (!s->snap_direct && ensure_staging(s)) return NB_EHIP;
     // aos_dev is free again: the previous snapshot was waited for, and nb_sync / nb_upload synchronise before returning
     int rc = launch_pack(s);
@@ -1203,13 +1335,13 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
     if (bind(s)) return NB_EHIP;
     int rc = nb_snapshot_wait(s);                     // aos_dev / staging may still be feeding a pipelined snapshot
     if (rc) return rc;
-    const bool direct = is_pinned_host(out);
+    const size_t bytes = s->i_count * sizeof(nb_body);
+    const bool direct = pinned_covers(out, bytes);
     if (!direct && ensure_staging(s)) return NB_EHIP;
     if ((rc = launch_pack(s))) return rc;
-    HIPCHK(hipMemcpyAsync(direct ? (void *)out : s->staging, s->aos_dev, s->i_count * sizeof(nb_body), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    if (!direct) memcpy(out, s->staging, s->i_count * sizeof(nb_body));
-    return NB_OK;
+    // registered destination: one DMA; pageable destination: staged in pieces, the host copies piece k out while
+    // piece k + 1 is still in flight
+    return copy_d2h(s, out, s->aos_dev, bytes, s->stream, direct ? nullptr : s->staging);
 }
 
 extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
@@ -1220,21 +1352,18 @@ extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
     if (ensure_staging(s)) return NB_EHIP;
     const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
     const size_t bytes = s->i_count * (s->dims3 ? 3 : 2) * sizeof(float);       // (x, y) or (x, y, z) per body
+    const void *src = s->aos_dev;
     if (s->dims3) {
         if (s->fp64) pack_positions3<double><<<g, BLOCK, 0, s->stream>>>((float *)s->aos_dev, (const double4 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
         else         pack_positions3<float><<<g, BLOCK, 0, s->stream>>>((float *)s->aos_dev, (const float4 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, bytes, hipMemcpyDeviceToHost, s->stream));
     } else if (s->fp64) {
         pack_positions<double><<<g, BLOCK, 0, s->stream>>>((float2 *)s->aos_dev, (const double2 *)s->pos[s->cur], (uint32_t)s->i_begin, ic);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(s->staging, s->aos_dev, bytes, hipMemcpyDeviceToHost, s->stream));
     } else {
-        HIPCHK(hipMemcpyAsync(s->staging, (const float2 *)s->pos[s->cur] + s->i_begin, bytes, hipMemcpyDeviceToHost, s->stream));
+        src = (const float2 *)s->pos[s->cur] + s->i_begin;        // fp32 2-D positions are already (x, y) floats
     }
-    HIPCHK(hipStreamSynchronize(s->stream));
-    memcpy(out_xy, s->staging, bytes);
-    return NB_OK;
+    return copy_d2h(s, out_xy, src, bytes, s->stream, s->staging);
 }
 
 extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
@@ -1267,22 +1396,84 @@ extern "C" int nb_energy(nb_sim *s, double *kinetic, double *potential)
     return NB_OK;
 }
 
+extern "C" int nb_momentum(nb_sim *s, double *p_xyz, double *l_z)
+{
+    if (!s || !p_xyz) return nb_fail(NB_EINVAL, "nb_momentum: NULL argument");
+    if (bind(s)) return NB_EHIP;
+    const uint32_t g = (uint32_t)s->ered_blocks;
+    if (!s->pred_dev) HIPCHK(hipMalloc((void **)&s->pred_dev, 4 * (size_t)g * sizeof(double)));
+    if (s->dims3 && s->fp64)
+        momentum_partials3<double><<<g, BLOCK, 0, s->stream>>>((const double4 *)s->pos[s->cur], (const double4 *)s->vel, (uint32_t)s->i_begin, (uint32_t)s->i_count, s->pred_dev);
+    else if (s->dims3)
+        momentum_partials3<float><<<g, BLOCK, 0, s->stream>>>((const float4 *)s->pos[s->cur], (const float4 *)s->vel, (uint32_t)s->i_begin, (uint32_t)s->i_count, s->pred_dev);
+    else if (s->fp64)
+        momentum_partials<double><<<g, BLOCK, 0, s->stream>>>((const double2 *)s->pos[s->cur], (const double *)s->mass, (const double2 *)s->vel,
+                                                              (uint32_t)s->i_begin, (uint32_t)s->i_count, s->pred_dev);
+    else
+        momentum_partials<float><<<g, BLOCK, 0, s->stream>>>((const float2 *)s->pos[s->cur], (const float *)s->mass, (const float2 *)s->vel,
+                                                             (uint32_t)s->i_begin, (uint32_t)s->i_count, s->pred_dev);
+    HIPCHK(hipGetLastError());
+    std::vector<double> h(4 * (size_t)g);
+    { const int rc = copy_d2h(s, h.data(), s->pred_dev, h.size() * sizeof(double)); if (rc) return rc; }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 4; ++c)
+        for (uint32_t b = 0; b < g; ++b) acc[c] += h[(size_t)c * g + b];
+    p_xyz[0] = acc[0]; p_xyz[1] = acc[1]; p_xyz[2] = acc[2];
+    if (l_z) *l_z = acc[3];
+    return NB_OK;
+}
+
 extern "C" uint64_t nb_frame(const nb_sim *s) { return s ? s->frame : 0; }
 extern "C" size_t nb_count(const nb_sim *s) { return s ? s->n : 0; }
 extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
 extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
 extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+// ---- in-process exchanges (one host process drives all the handles; no RCCL) -------------------------------------
+// Everything below is STREAM-ORDERED: the handles' streams wait for each other through events, the host never blocks.
+// cross_fence: every handle's stream waits for the work enqueued so far on every other handle's stream.
+static int cross_fence(nb_sim *const *sims, int count, int which)
+{
+    for (int a = 0; a < count; ++a) {
+        nb_sim *s = sims[a];
+        if (bind(s)) return NB_EHIP;
+        if (!s->ev_x[which]) HIPCHK(hipEventCreateWithFlags(&s->ev_x[which], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(s->ev_x[which], s->stream));
+    }
+    for (int a = 0; a < count; ++a) {
+        if (bind(sims[a])) return NB_EHIP;
+        for (int b = 0; b < count; ++b)
+            if (b != a) HIPCHK(hipStreamWaitEvent(sims[a]->stream, sims[b]->ev_x[which], 0));
+    }
+    return NB_OK;
+}
+
+// Kernels of handle s read the peers' buffers directly: map them.  Only "already enabled" is not an error — on a node
+// that refuses peer access the caller gets NB_EHIP here instead of a faulting kernel later.
+static int enable_peers(nb_sim *s, nb_sim *const *sims, int count)
+{
+    for (int r = 0; r < count; ++r) {
+        const int d = sims[r]->dev;
+        if (d == s->dev || d >= 64 || (s->peers_enabled >> d & 1u)) continue;
+        int can = 0;
+        HIPCHK(hipDeviceCanAccessPeer(&can, s->dev, d));
+        if (!can) return nb_fail(NB_EHIP, "device %d cannot access device %d's memory (no peer access): in-process exchange impossible", s->dev, d);
+        const hipError_t e = hipDeviceEnablePeerAccess(d, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else if (e != hipSuccess) { (void)hipGetLastError(); return nb_fail(NB_EHIP, "hipDeviceEnablePeerAccess(%d) on device %d: %s", d, s->dev, hipGetErrorString(e)); }
+        s->peers_enabled |= (uint64_t)1 << d;
+    }
+    return NB_OK;
+}
+
 extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
 {
     if (!sims || count < 1) return nb_fail(NB_EINVAL, "nb_exchange_positions: no handles");
-    for (int a = 0; a < count; ++a) {
-        if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz) {
+    for (int a = 0; a < count; ++a)
+        if (!sims[a] || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz)
             return nb_fail(NB_EINVAL, "nb_exchange_positions: handles must shard the same system");
-        }
-        if (bind(sims[a])) return NB_EHIP;
-        HIPCHK(hipStreamSynchronize(sims[a]->stream));           // owner's new block is complete
-    }
+    int rc = cross_fence(sims, count, 0);                        // every owner's new block is complete before anyone copies it
+    if (rc) return rc;
     for (int o = 0; o < count; ++o) {
         const nb_sim *own = sims[o];
         const char *src = (const char *)own->pos[own->cur] + own->i_begin * own->esz;
@@ -1294,11 +1485,7 @@ extern "C" int nb_exchange_positions(nb_sim *const *sims, int count)
                                       own->i_count * own->esz, dst->stream));
         }
     }
-    for (int a = 0; a < count; ++a) {
-        if (bind(sims[a])) return NB_EHIP;
-        HIPCHK(hipStreamSynchronize(sims[a]->stream));
-    }
-    return NB_OK;
+    return cross_fence(sims, count, 1);                          // nobody overwrites a block that is still being copied
 }
 
 extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
@@ -1310,15 +1497,14 @@ extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
             sims[a]->p.shard_world != count || sims[a]->p.shard_rank != a) {
             return nb_fail(NB_EINVAL, "nb_exchange_accelerations: needs the `count` handles of one symmetric sharded run, in rank order");
         }
-        if (bind(sims[a])) return NB_EHIP;
-        HIPCHK(hipStreamSynchronize(sims[a]->stream));           // its partial accelerations are complete
         src.p[a] = sims[a]->acc_full;
     }
+    int rc = cross_fence(sims, count, 0);                        // all partial accelerations are complete
+    if (rc) return rc;
     for (int o = 0; o < count; ++o) {
         nb_sim *s = sims[o];
         if (bind(s)) return NB_EHIP;
-        for (int r = 0; r < count; ++r)                          // peers' memory must be mapped on this device
-            if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+        if ((rc = enable_peers(s, sims, count))) return rc;
         const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
         if (s->dims3 && s->fp64) sum_partials<double4><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (double4 *)s->acc_owned);
         else if (s->dims3)       sum_partials<float4><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float4 *)s->acc_owned);
@@ -1326,11 +1512,7 @@ extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
         else                     sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, (uint32_t)s->i_begin, ic, (float2 *)s->acc_owned);
         HIPCHK(hipGetLastError());
     }
-    for (int a = 0; a < count; ++a) {
-        if (bind(sims[a])) return NB_EHIP;
-        HIPCHK(hipStreamSynchronize(sims[a]->stream));
-    }
-    return NB_OK;
+    return cross_fence(sims, count, 1);                          // acc_full may be rewritten only after every peer has read it
 }
 
 extern "C" int nb_shard_protocol(const nb_sim *s)
@@ -1351,15 +1533,14 @@ extern "C" int nb_exchange_allreduce(nb_sim *const *sims, int count)
         if (!sims[a] || !sims[a]->sym_replicated || sims[a]->n != sims[0]->n || sims[a]->esz != sims[0]->esz ||
             sims[a]->p.shard_world != count || sims[a]->p.shard_rank != a)
             return nb_fail(NB_EINVAL, "nb_exchange_allreduce: needs the `count` handles of one replicated (NB_FLAG_SHARD_ALLREDUCE) run, in rank order");
-        if (bind(sims[a])) return NB_EHIP;
-        HIPCHK(hipStreamSynchronize(sims[a]->stream));
         src.p[a] = sims[a]->acc_full;
     }
+    int rc = cross_fence(sims, count, 0);
+    if (rc) return rc;
     for (int o = 0; o < count; ++o) {               // sums into each handle's scratch (its `partial` array) ...
         nb_sim *s = sims[o];
         if (bind(s)) return NB_EHIP;
-        for (int r = 0; r < count; ++r)
-            if (sims[r]->dev != s->dev) { hipError_t e = hipDeviceEnablePeerAccess(sims[r]->dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+        if ((rc = enable_peers(s, sims, count))) return rc;
         const uint32_t nn = (uint32_t)s->n, g = (nn + BLOCK - 1) / BLOCK;
         if (s->dims3 && s->fp64) sum_partials<double4><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (double4 *)s->partial);
         else if (s->dims3)       sum_partials<float4><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float4 *)s->partial);
@@ -1367,13 +1548,12 @@ extern "C" int nb_exchange_allreduce(nb_sim *const *sims, int count)
         else                     sum_partials<float2><<<g, BLOCK, 0, s->stream>>>(src, count, 0u, nn, (float2 *)s->partial);
         HIPCHK(hipGetLastError());
     }
-    for (int a = 0; a < count; ++a) { if (bind(sims[a])) return NB_EHIP; HIPCHK(hipStreamSynchronize(sims[a]->stream)); }
-    for (int o = 0; o < count; ++o) {               // ... and only then over the inputs
+    if ((rc = cross_fence(sims, count, 1))) return rc;           // ... and only when every handle has read every input
+    for (int o = 0; o < count; ++o) {               // over the inputs
         nb_sim *s = sims[o];
         if (bind(s)) return NB_EHIP;
         HIPCHK(hipMemcpyAsync(s->acc_full, s->partial, s->n * s->esz, hipMemcpyDeviceToDevice, s->stream));
     }
-    for (int a = 0; a < count; ++a) { if (bind(sims[a])) return NB_EHIP; HIPCHK(hipStreamSynchronize(sims[a]->stream)); }
     return NB_OK;
 }
 extern "C" void *nb_acc_buffer(nb_sim *s, int which)

@@ -1086,4 +1086,44 @@ void energy_partials(const typename vec2_of<real>::type *__restrict__ pos, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// momentum — Body::momentum (Body.hpp:103-106: mass * vel) summed over the owned block in fp64, plus the angular
+// momentum about the origin Lz = sum m (x vy - y vx).  psum is [4][blocks]: px | py | pz (0 in 2-D) | Lz; per-block
+// partials are summed on the host in block order (deterministic), like the energy.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void block_reduce4(double (&v)[4], double *__restrict__ out, uint32_t blocks)
+{
+    __shared__ double red[4][BLOCK / 64];
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+        if ((t & 63) == 0) red[c][t >> 6] = v[c];
+    }
+    __syncthreads();
+    if (t < 4) {
+        double a = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) a += red[t][w];
+        out[(size_t)t * blocks + blockIdx.x] = a;
+    }
+}
+
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void momentum_partials(const typename vec2_of<real>::type *__restrict__ pos, const real *__restrict__ mass,
+                       const typename vec2_of<real>::type *__restrict__ vel, uint32_t i_begin, uint32_t i_count,
+                       double *__restrict__ psum)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (li < i_count) {
+        const double m = (double)mass[i_begin + li];
+        const double x = (double)pos[i_begin + li].x, y = (double)pos[i_begin + li].y;
+        const double vx = (double)vel[li].x, vy = (double)vel[li].y;
+        v[0] = m * vx; v[1] = m * vy; v[3] = m * (x * vy - y * vx);
+    }
+    block_reduce4(v, psum, gridDim.x);
+}
+
 } // namespace nbk

@@ -605,4 +605,22 @@ void energy_partials3(const typename vec4_of<real>::type *__restrict__ pos, cons
     }
 }
 
+// momentum of the owned block (see momentum_partials): px | py | pz | Lz (z component of x cross m v)
+template <typename real>
+__global__ __launch_bounds__(BLOCK)
+void momentum_partials3(const typename vec4_of<real>::type *__restrict__ pos, const typename vec4_of<real>::type *__restrict__ vel,
+                        uint32_t i_begin, uint32_t i_count, double *__restrict__ psum)
+{
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (li < i_count) {
+        const auto p = pos[i_begin + li];
+        const auto w = vel[li];
+        const double m = (double)p.w;
+        v[0] = m * (double)w.x; v[1] = m * (double)w.y; v[2] = m * (double)w.z;
+        v[3] = m * ((double)p.x * (double)w.y - (double)p.y * (double)w.x);
+    }
+    block_reduce4(v, psum, gridDim.x);
+}
+
 } // namespace nbk

@@ -110,17 +110,20 @@ public:
         quadtree.e_sq = epsilon * epsilon;
         sim_ = nb_create(reinterpret_cast<const nb_body *>(bodies.data()), bodies.size(), &p);
         if (!sim_) throw std::runtime_error(std::string("nb_create: ") + nb_last_error());
-        pin();
     }
     ~Simulation()
     {
         if (snapshot_in_flight_) (void)nb_snapshot_wait(sim_);
-        unpin();
-        if (pinned_back_) (void)nb_host_unregister(pinned_back_);
         nb_destroy(sim_);
     }
     Simulation(const Simulation &) = delete;
     Simulation &operator=(const Simulation &) = delete;
+
+    // HOST MEMORY.  `bodies` is an ordinary std::vector, as in the reference (the caller copies it by value,
+    // main.cpp:625); its storage is the heap's, may move whenever the caller assigns or swaps the vector, and shares
+    // its first and last page with other heap data.  The adaptor therefore never page-locks it (no hipHostRegister of
+    // memory it does not own page-wise, nothing to unregister after a reallocation): nb_sync / nb_snapshot_wait fill it
+    // from the library's own page-locked staging buffer, the host copy pipelined against the DMA.
 
     // Simulation.hpp:67-75 — on return `bodies` is coherent (pos, vel, acc, mass, radius).
     // `bodies` is public in the reference and stays public here, but the device state has a fixed size: a caller
@@ -129,7 +132,6 @@ public:
     {
         check_size();
         if (snapshot_in_flight_) { check(nb_snapshot_wait(sim_), "nb_snapshot_wait"); snapshot_in_flight_ = false; }
-        if (bodies.data() != pinned_) pin();   // the vector's storage moved (same size): re-register it
         const float current_dt = SIMULATION_DT.load();
         check(nb_step(sim_, current_dt, 1), "nb_step");
         check(nb_sync(sim_, reinterpret_cast<nb_body *>(bodies.data())), "nb_sync");
@@ -137,22 +139,22 @@ public:
     }
 
     // Pipelined form of step() for a viewer that can draw one frame late: advances one step and returns with `bodies`
-    // holding the state after the PREVIOUS call's step; the device-to-host copy of frame k (16.8 MB at N = 262 144)
-    // runs on a copy stream while the force of step k + 1 computes (nb_snapshot_begin / nb_snapshot_wait).
-    // The transfer lands in a second, page-locked vector that is swapped with `bodies` (O(1)) once it is complete,
-    // so the caller never reads a vector the copy engine is writing.  Call sync() to catch up to the current frame.
+    // holding the state after the PREVIOUS call's step.  The device-to-host copy of frame k (16.8 MB at N = 262 144)
+    // runs on a copy stream into the library's page-locked staging buffer while the force of step k + 1 computes
+    // (nb_snapshot_begin); nb_snapshot_wait then moves it into a PRIVATE vector — also while step k + 1 is running,
+    // because that step was enqueued first — which is swapped with `bodies` (O(1)).  The destination of a snapshot in
+    // flight is never the public vector, whose storage the caller may move at any time.  Call sync() to catch up.
     void step_overlapped()
     {
         check_size();
-        if (back_.size() != bodies.size()) {                   // first use: the second host buffer
-            back_ = bodies;
-            if (nb_host_register(back_.data(), back_.size() * sizeof(Body)) == NB_OK) pinned_back_ = back_.data();
+        if (back_.size() != bodies.size()) {
+            if (snapshot_in_flight_) { check(nb_snapshot_wait(sim_), "nb_snapshot_wait"); snapshot_in_flight_ = false; }
+            back_.assign(bodies.size(), Body());
         }
         check(nb_step(sim_, SIMULATION_DT.load(), 1), "nb_step");                                   // enqueue step k + 1
         if (snapshot_in_flight_) {
-            check(nb_snapshot_wait(sim_), "nb_snapshot_wait");                                      // frame k has arrived in back_
+            check(nb_snapshot_wait(sim_), "nb_snapshot_wait");                                      // frame k -> back_ (GPU busy with k + 1)
             bodies.swap(back_);
-            std::swap(pinned_, pinned_back_);
         }
         check(nb_snapshot_begin(sim_, reinterpret_cast<nb_body *>(back_.data())), "nb_snapshot_begin");   // frame k + 1 follows it
         snapshot_in_flight_ = true;
@@ -193,21 +195,7 @@ private:
             throw std::length_error("Simulation::bodies was resized (" + std::to_string(bodies.size()) + " != " +
                                     std::to_string(nb_count(sim_)) + "): the device state has a fixed body count");
     }
-    // page-lock the vector's storage so nb_sync DMAs straight into it
-    void pin()
-    {
-        unpin();
-        if (!bodies.empty() && nb_host_register(bodies.data(), bodies.size() * sizeof(Body)) == NB_OK) pinned_ = bodies.data();
-    }
-    // NOTE: if the vector reallocated, the old block is already freed: hipHostUnregister of it fails harmlessly
-    // (the runtime dropped the mapping with the pages or reports "not registered"); the error is ignored.
-    void unpin()
-    {
-        if (pinned_) { (void)nb_host_unregister(pinned_); pinned_ = nullptr; }
-    }
     nb_sim *sim_ = nullptr;
-    Body *pinned_ = nullptr;
-    std::vector<Body> back_;            // step_overlapped(): the buffer the in-flight snapshot is written to
-    Body *pinned_back_ = nullptr;
+    std::vector<Body> back_;            // step_overlapped(): private destination of the snapshot in flight
     bool snapshot_in_flight_ = false;
 };

@@ -160,6 +160,13 @@ class Simulation:
         L.check("nb_energy", self._lib.nb_energy(self._h, C.byref(k), C.byref(u)))
         return k.value, u.value
 
+    def momentum(self) -> tuple:
+        """((px, py, pz), Lz): total linear momentum (``Body::momentum``, Body.hpp:103-106, summed; fp64 on the
+        device) and angular momentum about the origin of the owned block."""
+        p, lz = (C.c_double * 3)(), C.c_double()
+        L.check("nb_momentum", self._lib.nb_momentum(self._h, p, C.byref(lz)))
+        return (p[0], p[1], p[2]), lz.value
+
     def dump(self, path: str) -> None:
         L.check("nb_dump", self._lib.nb_dump(self._h, str(path).encode()))
 

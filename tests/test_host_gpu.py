@@ -69,18 +69,57 @@ def test_cxx_adaptor_with_reference_caller_pattern():
 
 
 def test_sync_into_page_locked_host_memory_is_identical():
+    """nb_sync into the three kinds of destination: a pageable numpy array (pipelined staging), a block from
+    nb_host_alloc, and a caller-owned page-aligned range registered with nb_host_register (both DMA'd directly)."""
+    import mmap
     lib = nb.load()
-    ic = nb.plummer_2d(10000, 3)
+    n = 10000                                     # 640 000 bytes: not a whole number of pages -> register a rounded-up mapping
+    ic = nb.plummer_2d(n, 3)
     with nb.Simulation(ic, eps=0.05) as sim:
         sim.advance(3, 1e-3)
         plain = sim.sync().tobytes()
-        pinned = nb.bodies_array(10000)
-        L.check("nb_host_register", lib.nb_host_register(pinned.ctypes.data, pinned.nbytes))
+        with nb.PinnedBodies(n) as pb:
+            L.check("nb_sync", lib.nb_sync(sim._h, pb.array.ctypes.data))
+            assert pb.array.tobytes() == plain
+            pos = np.empty((n, 2), np.float32)
+            L.check("nb_sync_positions", lib.nb_sync_positions(sim._h, pos.ctypes.data))
+            assert np.array_equal(pos, pb.array["pos"])
+        page = mmap.PAGESIZE
+        size = -(-n * 64 // page) * page
+        m = mmap.mmap(-1, size)                   # anonymous mapping: page-aligned, whole pages, owned by this test
+        arr = np.frombuffer(m, dtype=L.BODY_DTYPE, count=n)
+        L.check("nb_host_register", lib.nb_host_register(arr.ctypes.data, size))
         try:
-            L.check("nb_sync", lib.nb_sync(sim._h, pinned.ctypes.data))
-            assert pinned.tobytes() == plain
+            L.check("nb_sync", lib.nb_sync(sim._h, arr.ctypes.data))
+            assert arr.tobytes() == plain
+            assert lib.nb_host_register(arr.ctypes.data, size) == L.NB_ESTATE          # already registered
         finally:
-            L.check("nb_host_unregister", lib.nb_host_unregister(pinned.ctypes.data))
+            L.check("nb_host_unregister", lib.nb_host_unregister(arr.ctypes.data))
+        del arr
+        m.close()
+
+
+def test_host_register_refuses_ranges_that_are_not_whole_pages():
+    """a registration pins whole pages, so an unaligned heap array (whose first and last page
+    also hold its neighbours' data) is refused, as is unregistering something that was never registered; the array
+    is still a legal nb_sync / nb_upload / nb_snapshot_begin argument (staged)."""
+    lib = nb.load()
+    n = 40000
+    ic = nb.plummer_2d(n, 3)
+    out = nb.bodies_array(n)
+    if out.ctypes.data % 4096 == 0:               # numpy happened to hand out an aligned block: shift by one record
+        out = nb.bodies_array(n + 1)[1:]
+    assert lib.nb_host_register(out.ctypes.data, out.nbytes) == L.NB_EINVAL
+    assert "whole number" in L.last_error()
+    assert lib.nb_host_unregister(out.ctypes.data) == L.NB_EINVAL
+    assert lib.nb_host_free(out.ctypes.data) == L.NB_EINVAL
+    with nb.Simulation(ic, eps=0.05) as sim:      # register-refused array right next to a pageable upload source: the r2 sequence
+        sim.advance(2, 1e-3)
+        want = sim.sync().copy()
+        sim.upload(want)
+        L.check("nb_sync", lib.nb_sync(sim._h, out.ctypes.data))
+        for f in ("pos", "vel", "acc", "mass", "radius"):
+            assert np.array_equal(out[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
 @pytest.mark.parametrize("n,protocol,late_us", [(8192, "allgather", None), (65536, "symmetric", None), (65536, "symmetric", "40"),
@@ -162,9 +201,8 @@ def test_pipelined_snapshot_is_the_state_at_begin_and_overlaps_later_steps():
         sim.advance(2, 1e-3)
         want = sim.sync().copy()                      # frame 2
         for pinned in (False, True):
-            out = nb.bodies_array(40000)
-            if pinned:
-                L.check("nb_host_register", lib.nb_host_register(out.ctypes.data, out.nbytes))
+            pb = nb.PinnedBodies(40000) if pinned else None
+            out = pb.array if pinned else nb.bodies_array(40000)
             try:
                 sim.upload(want)                       # back to frame 2's state (acc is carried in the records)
                 sim.snapshot_begin(out)
@@ -177,8 +215,9 @@ def test_pipelined_snapshot_is_the_state_at_begin_and_overlaps_later_steps():
                 assert not np.array_equal(later["pos"], want["pos"])
                 sim.snapshot_wait()                    # nothing pending: no-op
             finally:
-                if pinned:
-                    L.check("nb_host_unregister", lib.nb_host_unregister(out.ctypes.data))
+                out = None
+                if pb is not None:
+                    pb.close()
 
 
 def test_cxx_adaptor_overlapped_step_delivers_the_same_frames_one_call_late():
