@@ -109,7 +109,7 @@ class DeviceSampler:
             for pw, fq, _ in self.files:
                 w = self._read(pw)
                 if w is not None and (best is None or w > best[0]):
-                    best = (w, self._read(fq), self._read(pw.replace("power1_input", "temp2_input")))
+                    best = (w, self._read(fq), self._read(pw.replace("power1_input", "temp2_input")), time.perf_counter())
             if best:
                 self.samples.append(best)
             self._stop.wait(self.period)
@@ -128,10 +128,34 @@ class DeviceSampler:
         fq = [s[1] * 1e-6 for s in self.samples if s[1]]
         cap = max((self._read(c) or 0.0) for _, _, c in self.files) * 1e-6
         tj = [s[2] * 1e-3 for s in self.samples if len(s) > 2 and s[2]]
-        return {"samples": len(pw), "power_w_mean": sum(pw) / len(pw), "power_w_max": max(pw), "power_cap_w": cap or None,
-                "sclk_mhz_mean": (sum(fq) / len(fq)) if fq else None, "sclk_mhz_min": min(fq) if fq else None,
-                "junction_temp_c_max": max(tj) if tj else None,
-                "source": "amdgpu hwmon power1_input / freq1_input sampled during the timed region (rank 0's view; busiest visible card)"}
+        k = max(1, len(self.samples) // 8)          # first / last eighth of the region: burst vs settled
+        edge = lambda part: {"power_w": sum(x[0] for x in part) * 1e-6 / len(part),
+                             "sclk_mhz": (sum(x[1] for x in part if x[1]) * 1e-6 / max(1, sum(1 for x in part if x[1]))) or None}
+        out = {"samples": len(pw), "power_w_mean": sum(pw) / len(pw), "power_w_max": max(pw), "power_cap_w": cap or None,
+               "sclk_mhz_mean": (sum(fq) / len(fq)) if fq else None, "sclk_mhz_min": min(fq) if fq else None,
+               "junction_temp_c_max": max(tj) if tj else None,
+               "at_start": edge(self.samples[:k]), "at_end": edge(self.samples[-k:]),
+               "source": "amdgpu hwmon power1_input / freq1_input sampled during the region (rank 0's view; busiest visible card)"}
+        # what limited the clock, from the samples themselves
+        if cap and fq:
+            near_cap = out["power_w_max"] >= 0.93 * cap
+            out["clock_limit"] = ("socket power at its cap: power-limited" if near_cap else
+                                  f"power stayed below the cap ({out['power_w_max']:.0f} of {cap:.0f} W) at {out['sclk_mhz_mean']:.0f} MHz mean: "
+                                  "the clock was NOT power-limited on this box (thermal / voltage-frequency limit of the part)")
+        return out
+
+
+def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler_period=0.02):
+    """The settled rate: at least `min_seconds` of back-to-back steps AFTER the driver's timed region (whose 20 steps
+    sit before the power controller has settled), with the device clock / power of exactly that stretch."""
+    steps = max(20, int(min_seconds * 1e3 / max(ms_per_step_hint, 1e-3)) + 1)
+    smp = DeviceSampler(period_s=sampler_period)
+    smp.start()
+    t0 = time.perf_counter()
+    advance(steps, dt)
+    wait()
+    el = time.perf_counter() - t0
+    return {"steps": steps, "seconds": el, "ms_per_step": el / steps * 1e3, "device_state": smp.stop()}
 
 
 def cpu_baseline(ic, n, target_s=10.0):
@@ -211,6 +235,11 @@ def main() -> None:
                     help="multi-GPU exchange: tune (default) times a few steps of the symmetric pair split (reduce-scatter + "
                          "all-gather) and of north_star's all-gather protocol before the timed region and keeps the faster; "
                          "the others force one")
+    ap.add_argument("--driver", default="tune", choices=["tune", "torch", "c"],
+                    help="multi-GPU step loop: torch = collectives through torch.distributed between the library's split-step calls; "
+                         "c = the library's own RCCL loop (nb_comm_step: one foreign call for all steps); tune (default) = both are "
+                         "candidates of the start-up timing")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s settled-rate measurement after the timed region")
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
@@ -258,8 +287,12 @@ def main() -> None:
             dist.reduce_scatter_tensor(scratch[:64].clone(), scratch, op=dist.ReduceOp.SUM)
         dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
+        if args.no_symmetry and args.protocol not in ("tune", "allgather"):
+            raise SystemExit("--no-symmetry with several ranks means the all-gather protocol")
         sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank,
-                                    protocol=args.protocol, tune_dt=DT, uniform_mass=not args.general_mass)
+                                    protocol="allgather" if args.no_symmetry else args.protocol, tune_dt=DT,
+                                    driver=args.driver if args.backend == "nccl" else "torch",
+                                    uniform_mass=not args.general_mass, dims=args.dims, sym_chunks_per_item=args.chunks_per_item)
         inner = sim.sim
         advance, wait = sim.advance, sim.wait
 
@@ -299,7 +332,6 @@ def main() -> None:
         inner.profile(False)
     phases = sim.phase_report() if (world > 1 and not args.no_kernel_events) else None
     k1, u1 = sim.energy()
-
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,19 +344,45 @@ def main() -> None:
         else:
             phases_max = None
 
+    # the settled rate, AFTER the timed region (never part of `value`); its step count derives from the MAX-reduced
+    # `elapsed`, so every rank runs the same number of steps
+    sustained = None
+    if not args.no_sustained:
+        events = world == 1 and not args.no_kernel_events       # per-launch events on the single-GPU path only (nb_step bounds their number)
+        if events:
+            inner.profile(True)
+        barrier()
+        sustained = sustained_rate(advance, wait, DT, elapsed / max(1, args.steps) * 1e3, sampler_period=0.02 if world == 1 else 0.1)
+        barrier()
+        if events:
+            sms, sl = inner.profile_read()
+            inner.profile(False)
+            if sl:
+                sustained["avg_launch_ms"] = sms / sl
+        if world > 1:
+            t = torch.tensor([sustained["seconds"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sustained["seconds"] = float(t[0])
+            sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
+
     # secondary figure, outside the timed region and not part of `value`: the same kernel without the equal-mass
     # specialisation (12 + 2 instead of 10 + 2 instructions per body): what a system with individual masses gets
-    general = None
+    general = general_unscaled = None
     if world == 1 and rank == 0 and not args.no_secondary and not args.general_mass and not args.no_kernel_events:
-        with nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
-                           symmetry=not args.no_symmetry, uniform_mass=False) as g:
-            g.advance(2, DT)
-            g.wait()
-            g.profile(True)
-            g.advance(max(4, args.steps // 2), DT)
-            g.wait()
-            gms, gl = g.profile_read()
-        general = {"avg_launch_ms": gms / gl, "launches": gl}
+        def secondary(**kw):
+            with nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
+                               symmetry=not args.no_symmetry, uniform_mass=False, **kw) as g:
+                g.advance(2, DT)
+                g.wait()
+                g.profile(True)
+                g.advance(max(4, args.steps // 2), DT)
+                g.wait()
+                gms, gl = g.profile_read()
+                scaled = "mass_scaled=1" in g.describe()
+            return {"avg_launch_ms": gms / gl, "launches": gl, "mass_scaled": scaled}
+        general = secondary()                              # what individual masses get by default (masses folded into the geometry where safe)
+        if general["mass_scaled"]:
+            general_unscaled = secondary(mass_scaling=False)   # the same with the per-pair mass multiplies kept (NB_FLAG_NO_MASS_SCALING)
     # second secondary figure: north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of
     # 256 — on the same workload (the symmetric kernel is this repo's faster replacement for it)
     lds_tiled = None
@@ -348,7 +406,8 @@ def main() -> None:
         um = "uniform_mass=1" in inner.describe()
         kernel = ("force_sym" if symmetric else "force_tiled") + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64")
         # force launches per step on this rank: 1 (single GPU) or up to 3 (local + cross + late / local + remote ranges)
-        pairs_this_rank = float(n // world) * float(n) * args.steps      # 1/world of the ordered pairs, whatever the protocol
+        owned = sim.plan.i_count if world > 1 else n                        # rank 0's block (ragged splits: ceil(n / world))
+        pairs_this_rank = float(owned) * float(n) * args.steps             # its share of the ordered pairs, whatever the protocol
         if launches and force_ms > 0 and world == 1:
             kern_s = force_ms * 1e-3
             avg_launch_ms = force_ms / launches
@@ -414,6 +473,7 @@ def main() -> None:
                 "backend": args.backend if world > 1 else None,
                 "protocol": getattr(sim, "protocol", None) if world > 1 else None,
                 "protocol_tuning": getattr(sim, "tuning", None) if world > 1 else None,
+                "driver": getattr(sim, "driver", None) if world > 1 else None,
                 "uniform_mass_specialisation": um,
                 "launch": inner.describe(),
             },
@@ -429,7 +489,8 @@ def main() -> None:
                 "executed_frac": executed / peak if executed else None,
                 "executed_flop_per_unordered_pair": ex["sym"][0 if um else 1] if symmetric else None,
                 "valu_busy": pmc.get("valu_busy") if pmc_ok else None,
-                "valu_busy_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc run of this command on an MI355X)" if pmc_ok else None,
+                "valu_busy_source": ("profiles/hbm_traffic.json: a separate rocprofv3 --pmc run of this command on ANOTHER MI355X box, "
+                                     "not a measurement of this run") if pmc_ok else None,
                 "traffic": traffic,
                 "traffic_source": "work plan: stationary slab rows + travelling partials written once per launch + positions read once",
                 "traffic_pmc": traffic_pmc,
@@ -438,8 +499,13 @@ def main() -> None:
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
                 "general_mass": ({**general, "frac": flop_per_pair * pairs_per_step / (general["avg_launch_ms"] * 1e-3) / 1e12 / peak,
-                                  "note": "same kernel without the equal-mass specialisation (individual masses): untimed secondary run"}
+                                  "note": "same kernel without the equal-mass specialisation (individual masses; mass_scaled = the masses "
+                                          "are folded into the pair geometry, 11 + 2 instructions per body): untimed secondary run"}
                                  if general else None),
+                "general_mass_unscaled": ({**general_unscaled,
+                                           "frac": flop_per_pair * pairs_per_step / (general_unscaled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
+                                           "note": "individual masses with both per-pair mass multiplies kept (12 + 2 per body, NB_FLAG_NO_MASS_SCALING)"}
+                                          if general_unscaled else None),
                 "one_sided_lds_tiled": ({**lds_tiled, "kernel": "force_tiled" + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64"),
                                          "frac": flop_per_pair * pairs_per_step / (lds_tiled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
                                          "note": "north_star's kernel design (every ordered pair, j-tiles of 256 in LDS) on the same workload: untimed secondary run"}
@@ -452,6 +518,11 @@ def main() -> None:
                 "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic) if traffic else None,
             },
             "device_state": device_state,
+            "sustained": ({**sustained, "value": float(n) * float(n) * sustained["steps"] / sustained["seconds"],
+                           "frac": (flop_per_pair * float(n) * float(n) / world / (sustained["ms_per_step"] * 1e-3) / 1e12 / peak),
+                           "note": "settled rate over >= 2 s of steps run AFTER the timed region (whole step, wall clock); the timed region "
+                                   "above is the driver's K steps and may sit in the power controller's burst window"}
+                          if sustained else None),
             "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                        "steps": args.warmup + args.steps},
         }

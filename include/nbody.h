@@ -103,7 +103,14 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          handle then uses the NB_SHARD_ALLGATHER protocol */
        NB_FLAG_NO_UNIFORM_MASS = 2,   /* keep the per-pair mass multiply even when all masses are equal */
        NB_FLAG_NO_GUIDED_TAIL  = 4,   /* symmetric planner: uniform work items (no finer items at the end) */
-       NB_FLAG_SHARD_ALLREDUCE = 8 }; /* with shard_world > 1 and i_count = n: the NB_SHARD_ALLREDUCE protocol below */
+       NB_FLAG_SHARD_ALLREDUCE = 8,   /* with shard_world > 1 and i_count = n: the NB_SHARD_ALLREDUCE protocol below */
+       NB_FLAG_NO_MASS_SCALING = 32,  /* individual masses: keep the per-pair mass multiplies of the symmetric fp32 kernel instead of
+                                         folding the masses into the pair geometry (nb_kernels.hip.h MM_SCALED: one multiply less per
+                                         pair, pair displacements rounded once more: 6e-8 |x| / |d| relative per pair force) */
+       NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
+                                         NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
+                                         the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange
+                                         path (nb_comm_*, nb_exchange_*) on a single GPU; never faster than a plain handle */
 
 /* ---- parameters ----------------------------------------------------------- */
 typedef struct nb_params {
@@ -311,6 +318,54 @@ int   nb_step_mid(nb_sim *s);      /* NB_SHARD_SYMMETRIC only (no-op otherwise):
 int   nb_step_finish(nb_sim *s);
 void *nb_pos_buffer(nb_sim *s, int which);   /* device pointer, n*(x,y) reals */
 void *nb_stream(nb_sim *s);                  /* hipStream_t in use */
+
+/* Element layout of the device buffers above: positions / accelerations are `reals_per_element` reals per particle
+ * (2: (x, y); 4 for dims = 3: {x, y, z, m} / {ax, ay, az, 0}) of `bytes_per_real` bytes (4 or 8). */
+int   nb_element_layout(const nb_sim *s, int *reals_per_element, int *bytes_per_real);
+int   nb_device(const nb_sim *s);            /* HIP device ordinal the handle lives on */
+int   nb_shard_rank(const nb_sim *s, int *world);   /* nb_params.shard_rank (and shard_world) the handle was created with */
+
+/* ---- C-level multi-GPU exchange over RCCL -----------------------------------------
+ * north_star / SURVEY §8e: "host code stays in C ... an RCCL all-gather of positions over xGMI each step, overlapped
+ * with local-tile force compute on a second HIP stream".  Replaces the reference's only fan-out, std::async over
+ * i-chunks inside one process (Simulation.hpp:180-213).  An nb_comm binds sharded handles to an RCCL communicator,
+ * gives each a communication stream, and runs the step loop of their protocol (nb_shard_protocol) entirely
+ * STREAM-ORDERED: force / kick / drift on the handle's stream, ncclAllGather / ncclReduceScatter / ncclAllReduce on
+ * the communication stream, HIP events between the two; the host only enqueues and never blocks inside the loop.
+ * Two ways to form the communicator:
+ *   nb_comm_create_all   ONE process drives all ranks, one handle per device (ncclCommInitAll); the collectives of a
+ *                        step are issued as one ncclGroup;
+ *   nb_comm_create_rank  one process per GPU (ncclCommInitRank): rank 0 calls nb_comm_unique_id and hands the
+ *                        NB_COMM_ID_BYTES to the other ranks out of band (a file, MPI, a torch.distributed broadcast).
+ * Handles: created with shard_rank / shard_world, rank r owning the block [r n/world, +n/world) (equal blocks, which
+ * the in-place all-gather and the reduce-scatter need), or all n particles for NB_SHARD_ALLREDUCE; an unsharded
+ * handle forms a communicator of one rank (its all-gather is RCCL's one-rank no-op).  RCCL is loaded at first use
+ * (librccl.so.1); without it nb_comm_create_* fail with NB_ENODEVICE — there is no other transport behind this API. */
+typedef struct nb_comm nb_comm;
+#define NB_COMM_ID_BYTES 128
+int      nb_comm_unique_id(void *id_out /* NB_COMM_ID_BYTES */);
+nb_comm *nb_comm_create_rank(nb_sim *s, const void *id, int rank, int world);
+nb_comm *nb_comm_create_all(nb_sim *const *sims, int count);
+/* Enqueue nsteps steps (dt <= 0 -> each handle's params.dt).  Returns as soon as everything is enqueued. */
+int      nb_comm_step(nb_comm *c, float dt, int nsteps);
+/* Make the handles' compute streams wait (on the device) for the collectives still in flight, so that nb_sync /
+ * nb_energy / nb_momentum / nb_wait on a handle see complete replicas; nb_comm_wait also blocks the host until
+ * everything enqueued on the compute and communication streams is done. */
+int      nb_comm_flush(nb_comm *c);
+int      nb_comm_wait(nb_comm *c);
+void     nb_comm_destroy(nb_comm *c);        /* waits; the handles stay valid and are destroyed by their owner */
+int      nb_comm_info(const nb_comm *c, int *protocol, int *world, int *local_handles, int *rccl_version);
+
+/* The schedule of ONE step as data: what nb_comm_step issues, in order (host-only view; the CPU tests check call order
+ * and element counts with it).  kind: NB_OP_*; handle: index into the process's handle list (-1 for the group ops);
+ * stream: 0 = the handle's compute stream, 1 = its communication stream; event: NB_EV_* (-1 if none);
+ * count: elements (reals) of a collective — per rank for all-gather (send) and reduce-scatter (receive). */
+typedef struct nb_comm_op { int32_t kind, handle, stream, event; uint64_t count; } nb_comm_op;
+enum { NB_OP_BEGIN = 0, NB_OP_MID = 1, NB_OP_FINISH = 2, NB_OP_RECORD = 3, NB_OP_WAIT = 4, NB_OP_ALLGATHER = 5,
+       NB_OP_REDUCE_SCATTER = 6, NB_OP_ALLREDUCE = 7, NB_OP_GROUP_START = 8, NB_OP_GROUP_END = 9 };
+enum { NB_EV_POS = 0, NB_EV_AG = 1, NB_EV_ACC = 2, NB_EV_RED = 3 };
+int nb_debug_comm_schedule(int protocol, int handles, uint64_t block_reals, uint64_t full_reals, int ag_pending,
+                           nb_comm_op *ops_out, size_t cap, size_t *count);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* When enabled, every force-kernel launch is bracketed by HIP events on the

@@ -28,7 +28,7 @@ NB_EXTRA_VCLAMP, NB_EXTRA_BOUNDARY = 1, 2
 NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
 NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1, 2, 3
-NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE = 1, 2, 4, 8
+NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE, NB_FLAG_SHARD_SINGLE, NB_FLAG_NO_MASS_SCALING = 1, 2, 4, 8, 16, 32
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(
@@ -125,6 +125,15 @@ SYM_ITEM_DTYPE = np.dtype([("tile", "<u4"), ("c0", "<u4"), ("cnt", "<u4"), ("s_r
 assert SYM_ITEM_DTYPE.itemsize == 32
 
 
+#: numpy view of ``nb_comm_op`` (24 bytes): one operation of the sharded step's schedule
+COMM_OP_DTYPE = np.dtype([("kind", "<i4"), ("handle", "<i4"), ("stream", "<i4"), ("event", "<i4"), ("count", "<u8")])
+assert COMM_OP_DTYPE.itemsize == 24
+NB_COMM_ID_BYTES = 128
+(NB_OP_BEGIN, NB_OP_MID, NB_OP_FINISH, NB_OP_RECORD, NB_OP_WAIT, NB_OP_ALLGATHER, NB_OP_REDUCE_SCATTER, NB_OP_ALLREDUCE,
+ NB_OP_GROUP_START, NB_OP_GROUP_END) = range(10)
+NB_EV_POS, NB_EV_AG, NB_EV_ACC, NB_EV_RED = range(4)
+
+
 #: every symbol include/nbody.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "nb_params_default": (None, [C.POINTER(nb_params)]),
@@ -162,6 +171,18 @@ PROTOTYPES = {
     "nb_exchange_accelerations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_exchange_allreduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_acc_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "nb_element_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_device": (C.c_int, [C.c_void_p]),
+    "nb_shard_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "nb_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "nb_comm_create_rank": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "nb_comm_create_all": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
+    "nb_comm_step": (C.c_int, [C.c_void_p, C.c_float, C.c_int]),
+    "nb_comm_flush": (C.c_int, [C.c_void_p]),
+    "nb_comm_wait": (C.c_int, [C.c_void_p]),
+    "nb_comm_destroy": (None, [C.c_void_p]),
+    "nb_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_debug_comm_schedule": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -220,6 +241,17 @@ def sym_plan(n: int, cus: int = 256, rank: int = 0, world: int = 1, tuning: "nb_
     items = np.zeros(info.items, SYM_ITEM_DTYPE)
     check("nb_debug_sym_plan", lib.nb_debug_sym_plan(n, cus, rank, world, tp, items.ctypes.data, info.items, C.byref(info)))
     return items, info.as_dict()
+
+
+def comm_schedule(protocol: int, handles: int, block_reals: int, full_reals: int, ag_pending: bool) -> np.ndarray:
+    """Host-only: the operations ``nb_comm_step`` issues for one step (``nb_debug_comm_schedule``), as a COMM_OP_DTYPE array."""
+    lib = load()
+    cnt = C.c_size_t()
+    check("nb_debug_comm_schedule", lib.nb_debug_comm_schedule(protocol, handles, block_reals, full_reals, int(ag_pending), None, 0, C.byref(cnt)))
+    ops = np.zeros(cnt.value, COMM_OP_DTYPE)
+    check("nb_debug_comm_schedule", lib.nb_debug_comm_schedule(protocol, handles, block_reals, full_reals, int(ag_pending),
+                                                               ops.ctypes.data, cnt.value, C.byref(cnt)))
+    return ops
 
 
 def check(where: str, rc: int) -> None:

@@ -93,6 +93,8 @@ struct nb_sim {
     bool acc_valid = false;         // KDK: acc holds a(x_cur)
     bool uniform_mass = false;      // every body has the same mass: the per-pair mass multiply is hoisted
     float um_mass = 0.f;
+    bool mass_scaled = false;       // individual masses folded into the pair geometry (MM_SCALED, nb_kernels.hip.h)
+    float *sigma = nullptr;         // m^(-1/2) per particle, for mass_scaled
 
     // symmetric path (force_sym_f32): work items and its two slab sets
     bool sym = false;
@@ -236,21 +238,31 @@ static bool sym_eligible(const nb_sim *s)
     return true;
 }
 
+// NB_FLAG_SHARD_SINGLE: the sharded protocols with one rank (shard_world = 1, the handle owns everything): the rank's
+// "share" is every pair, all of them local; the host-side exchange degenerates to copies.  Lets a one-GPU box run the
+// whole split-step + collective path (nb_comm_*, nb_exchange_*).
+static bool single_rank(const nb_sim *s)
+{
+    return (s->p.flags & NB_FLAG_SHARD_SINGLE) && s->p.shard_world == 1 && s->p.shard_rank == 0 && s->i_count == s->n;
+}
+
 static bool want_sym(const nb_sim *s)          // single handle owns everything
 {
-    return s->i_count == s->n && s->p.shard_world <= 1 && sym_eligible(s);
+    return s->i_count == s->n && s->p.shard_world <= 1 && !single_rank(s) && sym_eligible(s);
 }
 
 static bool want_sym_replicated(const nb_sim *s)  // rank of a run that all-reduces accelerations and integrates everything everywhere
 {
     const size_t w = (size_t)s->p.shard_world;
-    return (s->p.flags & NB_FLAG_SHARD_ALLREDUCE) && s->p.shard_world > 1 && s->i_count == s->n &&
-           s->p.integrator == NB_INTEGRATOR_KICK_DRIFT && sym_eligible(s) && s->n / w >= 2 * (size_t)SYM_SB && s->n % (w * SYM_SB) == 0;
+    if (!(s->p.flags & NB_FLAG_SHARD_ALLREDUCE) || s->i_count != s->n || s->p.integrator != NB_INTEGRATOR_KICK_DRIFT || !sym_eligible(s)) return false;
+    if (single_rank(s)) return true;
+    return s->p.shard_world > 1 && s->n / w >= 2 * (size_t)SYM_SB && s->n % (w * SYM_SB) == 0;
 }
 
 static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
 {
     const size_t w = (size_t)s->p.shard_world;
+    if (single_rank(s)) return !(s->p.flags & NB_FLAG_SHARD_ALLREDUCE) && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT && sym_eligible(s);
     return s->p.shard_world > 1 && s->i_count != s->n && sym_eligible(s) && s->n / w >= 2 * (size_t)SYM_SB &&
            s->n % (w * SYM_SB) == 0 && s->i_count == s->n / w && s->i_begin == (size_t)s->p.shard_rank * s->i_count;   // equal blocks of whole tiles
 }
@@ -500,7 +512,7 @@ static void free_all(nb_sim *s)
     for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : s->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (s->own_pos) { (void)hipFree(s->pos[0]); (void)hipFree(s->pos[1]); }
-    (void)hipFree(s->mass); (void)hipFree(s->radius);
+    (void)hipFree(s->mass); (void)hipFree(s->radius); (void)hipFree(s->sigma);
     (void)hipFree(s->vel); (void)hipFree(s->acc); (void)hipFree(s->partial);
     (void)hipFree(s->aos_dev); (void)hipFree(s->ered_dev); (void)hipFree(s->pred_dev);
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
@@ -529,6 +541,24 @@ static int do_upload(nb_sim *s, const nb_body *in)
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
+    // Individual masses: the symmetric fp32 kernel can fold them into the pair geometry (MM_SCALED: 11 + 2 instead of
+    // 12 + 2 instructions per body) when every mass is positive and sigma = m^(-1/2), sigma * (the kernels' padding
+    // coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all stay finite floats with room to spare.  Exact rsqrt only:
+    // the Quake mode keeps the reference's arithmetic.  NB_FLAG_NO_MASS_SCALING keeps the 12 + 2 body.
+    s->mass_scaled = false;
+    if (!s->uniform_mass && s->p.sum_order == NB_SUM_TILED && !needs_guard(s) && !s->fp64 && !s->dims3 &&
+        s->p.rsqrt_mode == NB_RSQRT_EXACT && !(s->p.flags & NB_FLAG_NO_MASS_SCALING)) {
+        double mmin = HUGE_VAL, mmax = 0.0;
+        bool finite = true;
+        for (size_t i = 0; i < s->n; ++i) {
+            const double m = (double)in[i].mass;
+            if (!(m == m) || m > 3.0e38) finite = false;
+            if (m < mmin) mmin = m;
+            if (m > mmax) mmax = m;
+        }
+        const double eps = (double)s->p.eps;
+        s->mass_scaled = finite && mmin >= 1e-30 && std::pow(mmax, 1.5) / (eps * eps * eps) <= 1e36;
+    }
     { const int rc = copy_h2d(s, s->aos_dev, in, s->n * sizeof(nb_body)); if (rc) return rc; }
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
@@ -549,6 +579,11 @@ static int do_upload(nb_sim *s, const nb_body *in)
                                                             (uint32_t)s->i_begin, (uint32_t)s->i_count);
     }
     HIPCHK(hipGetLastError());
+    if (s->mass_scaled) {
+        if (!s->sigma) HIPCHK(hipMalloc((void **)&s->sigma, s->n * sizeof(float)));
+        mass_sigma<<<g, BLOCK, 0, s->stream>>>((const float *)s->mass, s->sigma, n);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(s->stream));  // `in` may be pageable and freed by the caller
     s->acc_valid = false;
     return NB_OK;
@@ -576,7 +611,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_NO_MASS_SCALING)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 ||
         (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {
@@ -718,14 +753,22 @@ static void launch_tiled_f32(nb_sim *s, const ForceJob &j, float eps2)
     if constexpr (!GUARD) {
         if (s->uniform_mass) {
             force_tiled_f32<P, RSQ, false, 8, true, F32_WS><<<grid, BLOCK, 0, s->stream>>>(
-                (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+                (const float2 *)s->pos[s->cur], (const float *)s->mass, s->sigma, out,
                 (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, s->um_mass,
                 j.gap_begin, j.gap_len);
             return;
         }
+        if constexpr (RSQ == RSQ_EXACT) {
+            if (s->mass_scaled) {      // individual masses folded into the pair geometry: no mass multiply in the body
+                force_tiled_f32<P, RSQ_EXACT, false, 8, false, F32_WS, true><<<grid, BLOCK, 0, s->stream>>>(
+                    (const float2 *)s->pos[s->cur], (const float *)s->mass, s->sigma, out,
+                    (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f, j.gap_begin, j.gap_len);
+                return;
+            }
+        }
     }
     force_tiled_f32<P, RSQ, GUARD, 8, false, F32_WS><<<grid, BLOCK, 0, s->stream>>>(
-        (const float2 *)s->pos[s->cur], (const float *)s->mass, out,
+        (const float2 *)s->pos[s->cur], (const float *)s->mass, s->sigma, out,
         (uint32_t)s->i_begin, (uint32_t)s->i_count, j.j_begin, j.j_end, j.js, i_tiles, eps2, 1.0f, j.gap_begin, j.gap_len);
 }
 
@@ -779,12 +822,15 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         const float2 *pos = (const float2 *)s->pos[s->cur];
         const float *mass = (const float *)s->mass;
         float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
+        const float *sg = s->sigma;
         if (s->uniform_mass) {
-            if (quake) force_sym_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
-            else       force_sym_f32<RSQ_EXACT, true><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, s->um_mass);
+            if (quake) force_sym_f32<RSQ_QUAKE, MM_UNIFORM><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, s->um_mass);
+            else       force_sym_f32<RSQ_EXACT, MM_UNIFORM><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, s->um_mass);
+        } else if (s->mass_scaled) {                 // exact rsqrt only (decided at upload)
+            force_sym_f32<RSQ_EXACT, MM_SCALED><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
         } else {
-            if (quake) force_sym_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
-            else       force_sym_f32<RSQ_EXACT, false><<<count, BLOCK, 0, st>>>(pos, mass, items, ss, sr, n, eps2, 1.0f);
+            if (quake) force_sym_f32<RSQ_QUAKE, MM_GENERAL><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
+            else       force_sym_f32<RSQ_EXACT, MM_GENERAL><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
         }
     }
     HIPCHK(hipGetLastError());
@@ -1025,7 +1071,7 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_step_begin: NULL handle");
     if (s->in_step) return nb_fail(NB_ESTATE, "nb_step_begin: previous step not finished");
-    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && sharded(s)) return nb_fail(NB_EINVAL, "sharded stepping supports the kick-drift integrator only");
+    if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT) return nb_fail(NB_EINVAL, "nb_step_begin: split stepping is the kick-drift integrator's (a KDK handle steps with nb_step)");
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;
     const int rc = step_begin_enqueue(s);
@@ -1167,7 +1213,7 @@ extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_step: NULL handle");
     if (nsteps < 0) return nb_fail(NB_EINVAL, "nb_step: nsteps < 0");
-    if (sharded(s) || s->sym_replicated) return nb_fail(NB_ESTATE, "nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish");
+    if (sharded(s) || s->sym_replicated || s->sym_sharded) return nb_fail(NB_ESTATE, "nb_step: sharded handle — drive it with nb_step_begin / exchange / nb_step_finish");
     if (s->in_step) return nb_fail(NB_ESTATE, "nb_step: a split step is in flight");
     if (bind(s)) return NB_EHIP;
     const float h = dt > 0.0f ? dt : s->p.dt;
@@ -1429,6 +1475,19 @@ extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
 extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
 extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" int nb_device(const nb_sim *s) { return s ? s->dev : -1; }
+extern "C" int nb_shard_rank(const nb_sim *s, int *world)
+{
+    if (world) *world = s ? s->p.shard_world : 0;
+    return s ? s->p.shard_rank : -1;
+}
+extern "C" int nb_element_layout(const nb_sim *s, int *reals_per_element, int *bytes_per_real)
+{
+    if (!s) return nb_fail(NB_EINVAL, "nb_element_layout: NULL handle");
+    if (reals_per_element) *reals_per_element = s->dims3 ? 4 : 2;
+    if (bytes_per_real) *bytes_per_real = (int)s->rsz;
+    return NB_OK;
+}
 // ---- in-process exchanges (one host process drives all the handles; no RCCL) -------------------------------------
 // Everything below is STREAM-ORDERED: the handles' streams wait for each other through events, the host never blocks.
 // cross_fence: every handle's stream waits for the work enqueued so far on every other handle's stream.
@@ -1517,9 +1576,10 @@ extern "C" int nb_exchange_accelerations(nb_sim *const *sims, int count)
 
 extern "C" int nb_shard_protocol(const nb_sim *s)
 {
-    if (s && s->sym_replicated) return NB_SHARD_ALLREDUCE;
-    if (!s || s->i_count == s->n) return NB_SHARD_NONE;
-    return s->sym_sharded ? NB_SHARD_SYMMETRIC : NB_SHARD_ALLGATHER;
+    if (!s) return NB_SHARD_NONE;
+    if (s->sym_replicated) return NB_SHARD_ALLREDUCE;
+    if (s->sym_sharded) return NB_SHARD_SYMMETRIC;          // also the single-rank form (NB_FLAG_SHARD_SINGLE: i_count == n)
+    return s->i_count == s->n ? NB_SHARD_NONE : NB_SHARD_ALLGATHER;
 }
 
 // In-process all-reduce of the replicated protocol (a host that drives all `count` handles of one run itself):
@@ -1640,12 +1700,12 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d | symmetric=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
-             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass,
+             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
              (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;

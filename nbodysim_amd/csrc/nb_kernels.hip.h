@@ -208,9 +208,9 @@ void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar
 // Lane l (of i-lane group) of tile T owns particles
 //   i_begin + T*IT + p*(2*LANES_I) + 2l + {0,1},  p < P,  IT = LANES_I*2P,  LANES_I = 256/WS.
 // ---------------------------------------------------------------------------
-template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1, bool MS = false>
 __device__ __forceinline__
-void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass,
+void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                           float2 *__restrict__ partial,
                           uint32_t i_begin, uint32_t i_count,
                           uint32_t j_begin, uint32_t j_end,
@@ -218,6 +218,7 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                           uint32_t gap_begin = 0xffffffffu, uint32_t gap_len = 0)
 {
     static_assert(WS == 1 || WS == 2 || WS == 4, "WS waves share an i-set");
+    static_assert(!(MS && (UM || GUARD)), "mass scaling is for individual masses with eps > 0");
     constexpr uint32_t LANES_I = BLOCK / WS;          // distinct i-lanes in the workgroup
     constexpr uint32_t IT = LANES_I * 2 * P;          // particles per workgroup
     constexpr uint32_t JW = TJ / WS;                  // j's of a tile walked by one wave group
@@ -254,22 +255,22 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     const v2f e2 = {eps2, eps2};
 
     const uint32_t ntiles = (s1 - s0 + TJ - 1) / TJ;
-    // stage tile 0
-    {
-        const uint32_t j = s0 + t;
-        float2 pj = make_float2(PAD_XY, PAD_XY);
-        float mj = 0.f;
-        if (j < s1) { const uint32_t jg = j + (j >= gap_begin ? gap_len : 0u); pj = pos[jg]; mj = mass[jg]; }
-        tile[0][t] = (v4f){pj.x, pj.y, mj, mj};
-    }
+    // One j-particle as the LDS tile holds it: {x, y, m, m}; mass-scaled (MS, see MM_SCALED at force_sym_f32): the
+    // pre-multiplied position and the scaled softening {sigma x, sigma y, -sigma, sigma^2 eps^2}, sigma = m^(-1/2) —
+    // the body then needs no mass multiply at all (8 + 2 instructions per two pairs, like the equal-mass form).
+    auto stage = [&](uint32_t j) -> v4f {
+        if (j >= s1) return MS ? (v4f){PAD_XY, PAD_XY, -1.0f, eps2} : (v4f){PAD_XY, PAD_XY, 0.f, 0.f};
+        const uint32_t jg = j + (j >= gap_begin ? gap_len : 0u);
+        const float2 pj = pos[jg];
+        if constexpr (MS) { const float sg = sigma[jg]; return (v4f){pj.x * sg, pj.y * sg, -sg, (sg * sg) * eps2}; }
+        else { const float mj = mass[jg]; return (v4f){pj.x, pj.y, mj, mj}; }
+    };
+    tile[0][t] = stage(s0 + t);
     __syncthreads();
 
     for (uint32_t it = 0; it < ntiles; ++it) {
         // prefetch the next tile into registers while this one is consumed
-        float2 pn = make_float2(PAD_XY, PAD_XY);
-        float mn = 0.f;
-        const uint32_t jn1 = s0 + (it + 1) * TJ + t;
-        if (jn1 < s1) { const uint32_t jg = jn1 + (jn1 >= gap_begin ? gap_len : 0u); pn = pos[jg]; mn = mass[jg]; }
+        const v4f nxt = stage(s0 + (it + 1) * TJ + t);
 
         const v4f *__restrict__ cur = tile[it & 1] + w * JW;
 #pragma unroll UNROLL
@@ -278,10 +279,20 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
             const v2f xj = {q.x, q.x}, yj = {q.y, q.y}, mj = {q.z, q.w};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const v2f dx = xj - xi[p];         // v_pk_add_f32 (neg)
-                const v2f dy = yj - yi[p];
-                v2f r2, inv;
-                if constexpr (GUARD) {
+                v2f dx, dy, r2, inv;
+                if constexpr (MS) {
+                    const v2f ns = {q.z, q.z};
+                    dx = __builtin_elementwise_fma(ns, xi[p], xj);     // sigma_j (x_j - x_i)
+                    dy = __builtin_elementwise_fma(ns, yi[p], yj);
+                } else {
+                    dx = xj - xi[p];               // v_pk_add_f32 (neg)
+                    dy = yj - yi[p];
+                }
+                if constexpr (MS) {
+                    r2 = __builtin_elementwise_fma(dx, dx, (v2f){q.w, q.w});
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                } else if constexpr (GUARD) {
                     // eps == 0 or too small for 1/r^3 of a coincident pair to stay finite: keep the reference's
                     // `if (r_sq > 0)` around `fast_inv_sqrt(r_sq + e_sq)` (Quadtree.hpp:139-140)
                     r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
@@ -302,13 +313,13 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
                 }
                 const v2f inv2 = inv * inv;
                 v2f s;
-                if constexpr (UM) s = inv * inv2;           // 1 / r^3, the common mass is applied once at the end
+                if constexpr (UM || MS) s = inv * inv2;     // 1 / r^3 (UM: the common mass is applied once at the end; MS: g^3 carries m_j)
                 else s = (mj * inv) * inv2;                 // m / r^3
                 ax[p] = __builtin_elementwise_fma(s, dx, ax[p]);
                 ay[p] = __builtin_elementwise_fma(s, dy, ay[p]);
             }
         }
-        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = (v4f){pn.x, pn.y, mn, mn};
+        if (it + 1 < ntiles) tile[(it + 1) & 1][t] = nxt;
         __syncthreads();
     }
 
@@ -345,17 +356,17 @@ void force_tiled_f32_body(const float2 *__restrict__ pos, const float *__restric
     }
 }
 
-template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1>
+template <int P, int RSQ, bool GUARD, int UNROLL, bool UM = false, int WS = 1, bool MS = false>
 __global__ __launch_bounds__(BLOCK)
-void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                      float2 *__restrict__ partial,
                      uint32_t i_begin, uint32_t i_count,
                      uint32_t j_begin, uint32_t j_end,
                      uint32_t js, uint32_t i_tiles, float eps2, float um_mass,
                      uint32_t gap_begin, uint32_t gap_len)
 {
-    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM, WS>(pos, mass, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2,
-                                                        um_mass, gap_begin, gap_len);
+    force_tiled_f32_body<P, RSQ, GUARD, UNROLL, UM, WS, MS>(pos, mass, sigma, partial, i_begin, i_count, j_begin, j_end, js, i_tiles, eps2,
+                                                            um_mass, gap_begin, gap_len);
 }
 
 // ---------------------------------------------------------------------------
@@ -409,54 +420,89 @@ __device__ __forceinline__ float lane_rot(float v, int addr)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-template <int RSQ, bool UM, bool DIAG>
+// Mass handling of the symmetric fp32 kernels (template parameter MM):
+//   MM_UNIFORM  all bodies have the same mass: the per-pair mass multiplies are hoisted out of the body
+//               (10 packed + 2 v_rsq_f32 per two stationary particles x one travelling particle, both directions);
+//   MM_GENERAL  individual masses, applied per pair: si = m_j / r^3, sj = m_i / r^3 (12 + 2);
+//   MM_SCALED   individual masses folded into the GEOMETRY of the pair (11 + 2): the travelling particle j carries
+//               sigma_j = m_j^(-1/2) and its pre-multiplied position X_j = sigma_j x_j, and the pair is evaluated in
+//               coordinates stretched by sigma_j:   D = sigma_j (x_j - x_i) = fma(-sigma_j, x_i, X_j)   (the fma takes the
+//               place of the subtraction),  t = |D|^2 + sigma_j^2 eps^2,  g = rsq(t) = (r^2 + eps^2)^(-1/2) / sigma_j.
+//               Then g^3 D = m_j d / (r^2 + eps^2)^(3/2) IS the acceleration of the stationary particle — no multiply
+//               by m_j — and the travelling side accumulates m_i g^3 D = m_j (m_i d / (...)^(3/2)), divided by m_j
+//               (= multiplied by sigma_j^2) once per chunk.  One of the two per-pair mass multiplies is gone.
+//               Price: D is no longer an exact difference of two floats (X_j is rounded once: relative error
+//               6e-8 |x_j| / |d| of the pair's force), and m must be positive with m_max^(3/2) / eps^3 and 1 / m_min
+//               inside the float range — checked at upload (nb_capi.hip: mass_scaling_ok), otherwise MM_GENERAL runs.
+enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
+
+template <int RSQ, int MM, bool DIAG>
 __device__ __forceinline__
-void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
+void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
                 const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&mi)[SYM_P],
                 v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], float eps2, float um_mass, float2 (*red)[4][64])
 {
+    constexpr bool UM = MM == MM_UNIFORM, MS = MM == MM_SCALED;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     const int addr = (int)(((lane + 1u) & 63u) * 4u);    // pull from lane+1: particles move down one lane per step
     const v2f e2 = {eps2, eps2};
 
-    // chunk c0 into registers
-    float xq = PAD_XY, yq = PAD_XY, mq = 0.f;
-    {
-        const uint32_t j = c0 * SYM_CH + lane;
-        if (j < n) { const float2 pj = pos[j]; xq = pj.x; yq = pj.y; if constexpr (!UM) mq = mass[j]; }
-    }
+    // chunk c0 into registers.  MM_SCALED: (xq, yq) hold the PRE-MULTIPLIED position sigma (x, y), mq holds -sigma and
+    // eq = sigma^2 eps^2; padding lanes take sigma = 1 at PAD_XY (their g^3 underflows to 0 like everywhere else)
+    float xq = PAD_XY, yq = PAD_XY, mq = MS ? -1.0f : 0.f, eq = eps2;
+    auto fetch = [&](uint32_t j, float &x, float &y, float &m, float &e) {
+        x = PAD_XY; y = PAD_XY; m = MS ? -1.0f : 0.f; e = eps2;
+        if (j < n) {
+            const float2 pj = pos[j];
+            if constexpr (MS) { const float sg = sigma[j]; x = pj.x * sg; y = pj.y * sg; m = -sg; e = (sg * sg) * eps2; }
+            else { x = pj.x; y = pj.y; if constexpr (!UM) m = mass[j]; }
+        }
+    };
+    fetch(c0 * SYM_CH + lane, xq, yq, mq, eq);
     for (uint32_t c = 0; c < cnt; ++c) {
         // next chunk in flight behind the 64 steps
-        float xn = PAD_XY, yn = PAD_XY, mn = 0.f;
-        {
-            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
-            if (c + 1 < cnt && j < n) { const float2 pj = pos[j]; xn = pj.x; yn = pj.y; if constexpr (!UM) mn = mass[j]; }
-        }
+        float xn, yn, mn, en;
+        fetch(c + 1 < cnt ? (c0 + c + 1) * SYM_CH + lane : n, xn, yn, mn, en);
         v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};
 #pragma unroll SYM_UNROLL
         for (int step = 0; step < 64; ++step) {
             // positions of the next step do not depend on this step's arithmetic: rotate them early
             const float xr = lane_rot(xq, addr), yr = lane_rot(yq, addr);
-            float mr = 0.f;
+            float mr = 0.f, er = 0.f;
             if constexpr (!UM) mr = lane_rot(mq, addr);
+            if constexpr (MS) er = lane_rot(eq, addr);
             const v2f xj = {xq, xq}, yj = {yq, yq};
 #pragma unroll
             for (int p = 0; p < SYM_P; ++p) {
-                const v2f dx = xj - xi[p];
-                const v2f dy = yj - yi[p];
-                v2f r2 = __builtin_elementwise_fma(dx, dx, e2);
+                v2f dx, dy, r2;
+                if constexpr (MS) {
+                    const v2f ns = {mq, mq};                               // -sigma_j
+                    dx = __builtin_elementwise_fma(ns, xi[p], xj);         // sigma_j (x_j - x_i)
+                    dy = __builtin_elementwise_fma(ns, yi[p], yj);
+                    r2 = __builtin_elementwise_fma(dx, dx, (v2f){eq, eq});
+                } else {
+                    dx = xj - xi[p];
+                    dy = yj - yi[p];
+                    r2 = __builtin_elementwise_fma(dx, dx, e2);
+                }
                 r2 = __builtin_elementwise_fma(dy, dy, r2);
                 v2f inv;
                 if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
                 else inv = quake_rsqrt2(r2);
                 const v2f inv3 = inv * (inv * inv);
-                if constexpr (UM) {
+                if constexpr (UM || MS) {
                     ax[p] = __builtin_elementwise_fma(inv3, dx, ax[p]);
                     ay[p] = __builtin_elementwise_fma(inv3, dy, ay[p]);
                     if constexpr (!DIAG) {
-                        aqx = __builtin_elementwise_fma(-inv3, dx, aqx);
-                        aqy = __builtin_elementwise_fma(-inv3, dy, aqy);
+                        if constexpr (MS) {
+                            const v2f sj = mi[p] * inv3;                   // m_i g^3: the m_j it still carries is divided out per chunk
+                            aqx = __builtin_elementwise_fma(-sj, dx, aqx);
+                            aqy = __builtin_elementwise_fma(-sj, dy, aqy);
+                        } else {
+                            aqx = __builtin_elementwise_fma(-inv3, dx, aqx);
+                            aqy = __builtin_elementwise_fma(-inv3, dy, aqy);
+                        }
                     }
                 } else {
                     const v2f si = (v2f){mq, mq} * inv3;       // force ON the stationary pair: m_j / r^3
@@ -471,6 +517,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
             }
             xq = xr; yq = yr;
             if constexpr (!UM) mq = mr;
+            if constexpr (MS) eq = er;
             if constexpr (!DIAG) {
                 aqx.x = lane_rot(aqx.x, addr); aqx.y = lane_rot(aqx.y, addr);
                 aqy.x = lane_rot(aqy.x, addr); aqy.y = lane_rot(aqy.y, addr);
@@ -481,6 +528,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
             // combine the 4 waves (4 different stationary sets) in wave order and store once.
             float2 r = make_float2(aqx.x + aqx.y, aqy.x + aqy.y);
             if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; }
+            if constexpr (MS) { const float s2 = mq * mq; r.x *= s2; r.y *= s2; }      // / m_j: the particle is back in its home lane
             float2 (*rb)[64] = red[c & 1u];
             rb[w][lane] = r;
             __syncthreads();
@@ -494,16 +542,18 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass,
         }
         xq = xn; yq = yn;
         if constexpr (!UM) mq = mn;
+        if constexpr (MS) eq = en;
     }
 }
 
-template <int RSQ, bool UM>
+template <int RSQ, int MM>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
-void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass,
+void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                    const SymItem *__restrict__ items,
                    float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
                    uint32_t n, float eps2, float um_mass)
 {
+    constexpr bool UM = MM == MM_UNIFORM;
     __shared__ float2 red[2][4][64];
     const SymItem it = items[blockIdx.x];
     const bool diag = it.diag != 0;
@@ -525,8 +575,8 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
-    if (diag) sym_chunks<RSQ, UM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
-    else      sym_chunks<RSQ, UM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    if (diag) sym_chunks<RSQ, MM, true>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    else      sym_chunks<RSQ, MM, false>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
 
     float2 *__restrict__ out = slab_s + (size_t)s_row * SYM_SB;
 #pragma unroll
@@ -534,6 +584,14 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
         if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
         *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
     }
+}
+
+// sigma[i] = m_i^(-1/2) for the mass-scaled kernels (correctly rounded sqrt and divide)
+__global__ __launch_bounds__(BLOCK)
+void mass_sigma(const float *__restrict__ mass, float *__restrict__ sigma, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) sigma[i] = 1.0f / sqrtf(mass[i]);
 }
 
 // acc_sum[k] = sum of particle k's stationary rows (its tile's items held here, in item order;

@@ -50,6 +50,7 @@ import numpy as np
 from . import _lib as L
 
 PROTOCOLS = ("auto", "symmetric", "allgather", "allreduce", "tune")
+DRIVERS = ("torch", "c", "tune")
 
 
 @dataclass(frozen=True)
@@ -182,18 +183,26 @@ class DistributedSimulation:
                             agree by all-reduce): the symmetric split as the library would size it, the same with the
                             held-back "late" local items switched the other way (they hide the reduce-scatter; on by
                             default from 8 ranks), and the all-gather protocol
+    driver     "torch"      this module issues the collectives through torch.distributed (RCCL via ProcessGroupNCCL)
+                            between the library's split-step calls, one Python iteration per step
+               "c"          the library's own loop (``nb_comm_step``, nbodysim_amd/csrc/nb_comm.cpp): RCCL collectives on
+                            a communication stream, event-ordered, ONE foreign call for any number of steps; the RCCL
+                            id is created by rank 0 and broadcast through the torch process group.  RCCL only.
+               "tune"       (with protocol="tune") both drivers are candidates of the start-up timing
     Extra keyword arguments go to ``Simulation`` (``sym_late_us``, ``sym_chunks_per_item`` ... the tuning fields of
     ``nb_params``; they must be the same on every rank and are verified to be).
     """
 
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
                  order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
-                 protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, **sim_kwargs):
+                 protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, driver: str = "torch", **sim_kwargs):
         import torch
         import torch.distributed as dist
 
         if protocol not in PROTOCOLS:
             raise ValueError(f"protocol must be one of {PROTOCOLS}")
+        if driver not in DRIVERS:
+            raise ValueError(f"driver must be one of {DRIVERS}")
         self.dist = dist
         self.torch = torch
         self.group = group
@@ -218,19 +227,26 @@ class DistributedSimulation:
         self._phase_events: list = []
         self._host_enqueue_s = 0.0
         self._host_steps = 0
+        self.comm = None
+        self.driver = "torch"
 
         extra: dict = {}
         if protocol == "tune" and world > 1:
-            protocol, extra = self._tune(bodies, tune_steps, tune_dt)
+            protocol, extra, driver = self._tune(bodies, tune_steps, tune_dt, driver)
         elif protocol == "tune":
             protocol = "auto"
-        self._create(bodies, protocol, extra)
+        if driver == "tune":
+            driver = "torch"
+        self._create(bodies, protocol, extra, driver)
 
     # -- construction ---------------------------------------------------------
-    def _create(self, bodies: np.ndarray, protocol: str, extra: Optional[dict] = None) -> None:
+    def _create(self, bodies: np.ndarray, protocol: str, extra: Optional[dict] = None, driver: str = "torch") -> None:
         """Allocate the replicas, create the handle, and verify that every rank got the same pair split.  A rank
         whose nb_create fails still reaches the collective, so the job fails on every rank instead of hanging."""
         from .simulation import Simulation
+
+        if driver == "c" and self.plan.ragged:
+            raise RuntimeError("driver='c' needs equal blocks (world must divide n): nb_comm's in-place all-gather and reduce-scatter")
 
         torch, world, rank = self.torch, self.plan.world, self.plan.rank
         err: Optional[BaseException] = None
@@ -293,26 +309,72 @@ class DistributedSimulation:
         self._cur = 0          # index into self.pos of the library's CURRENT replica
         self._pending = None   # Work of the all-gather filling the CURRENT replica
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
+        self.driver = driver
+        self.comm = None
+        if driver == "c" and world > 1:
+            self._create_comm()
 
-    def _tune(self, bodies: np.ndarray, steps: int, dt: float):
+    def _create_comm(self) -> None:
+        """The library's own RCCL communicator for this run (``nb_comm_create_rank``): rank 0's id goes to the other
+        ranks through the torch process group; every rank reports success or failure before anyone proceeds."""
+        from .comm import Comm, unique_id
+
+        torch, dist, world, rank = self.torch, self.dist, self.plan.world, self.plan.rank
+        dev = _comm_device(self.group)
+        uid = torch.zeros(L.NB_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        err: Optional[BaseException] = None
+        if rank == 0:
+            try:
+                uid = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).to(dev)
+            except L.NBodyError as e:           # still take part in the broadcast: an all-zero id tells the others
+                err = e
+        dist.broadcast(uid, src=0, group=self.group)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        if err is None and any(raw):
+            try:
+                self.comm = Comm.rank(self.sim, raw, rank, world)
+            except L.NBodyError as e:
+                err = e
+        elif err is None:
+            err = RuntimeError("rank 0 could not create an RCCL id")
+        ok, lo, _ = ranks_agree([0 if err is not None else 1], self.group)
+        if not ok or lo[0] == 0:
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            self.sim.close()
+            self.sim = None
+            raise RuntimeError(f"rank {rank}: the C-level RCCL communicator could not be formed on every rank"
+                               + (f"; this rank: {err}" if err is not None else "")) from err
+
+    def _tune(self, bodies: np.ndarray, steps: int, dt: float, driver: str = "torch"):
         """Time `steps` steps of each candidate on a scratch copy of the system (2 untimed steps first), wall clock
         between barriers, MAX over ranks; the handles are destroyed again, so the simulation proper starts from
-        the caller's bodies at frame 0.  Returns (protocol, extra Simulation keyword arguments)."""
+        the caller's bodies at frame 0.  Returns (protocol, extra Simulation keyword arguments, driver).
+        A replicated (all-reduce) candidate must also pass the divergence check on this transport — every rank ends
+        the trial with bit-identical positions — or it is disqualified."""
         local: Dict[str, float] = {}
         late_default_on = self.plan.world >= 8 and float(self._args.get("sym_late_us", 0.0)) == 0.0
         flipped = ("symmetric-late", {"sym_late_us": -1.0}) if late_default_on else ("symmetric+late", {"sym_late_us": 40.0})
-        cands = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allreduce": ("allreduce", {}),
-                 "allgather": ("allgather", {})}
+        base = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allreduce": ("allreduce", {}),
+                "allgather": ("allgather", {})}
         if float(self._args.get("sym_late_us", 0.0)) != 0.0:      # the caller fixed the late share: nothing to flip
-            del cands[flipped[0]]
-        for name, (cand, extra) in cands.items():
-            if local.get("symmetric") == float("inf") and cand in ("symmetric", "allreduce"):
+            del base[flipped[0]]
+        nccl = self.dist.get_backend(self.group) == "nccl"
+        drivers = [d for d in (("torch", "c") if driver == "tune" else (driver,)) if d == "torch" or (nccl and not self.plan.ragged)]
+        cands = {}
+        for d in drivers:
+            for name, (cand, extra) in base.items():
+                cands[name if d == "torch" else "c:" + name] = (cand, extra, d)
+        for name, (cand, extra, d) in cands.items():
+            pre = "c:" if d == "c" else ""
+            if local.get(pre + "symmetric") == float("inf") and cand in ("symmetric", "allreduce"):
                 local[name] = float("inf")
                 continue
             try:
-                self._create(bodies, cand, extra)
+                self._create(bodies, cand, extra, d)
             except RuntimeError as e:
-                if "not eligible" not in str(e):
+                if "not eligible" not in str(e) and "communicator could not be formed" not in str(e):
                     raise
                 local[name] = float("inf")
                 continue
@@ -324,10 +386,30 @@ class DistributedSimulation:
             self.wait()
             self.dist.barrier(group=self.group)
             local[name] = (time.perf_counter() - t0) / steps
+            if self.replicated and not self.replicas_identical():
+                local[name] = float("inf")
             self.close()
-        best, job = agree_on_fastest(local, self.group)
+        prefer = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather")
+        best, job = agree_on_fastest(local, self.group, prefer=tuple("c:" + k for k in prefer) + prefer)
         self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best}
         return cands[best]
+
+    def replicas_identical(self) -> bool:
+        """Replicated (all-reduce) protocol: every rank integrates all n particles from an all-reduced sum, so the
+        replicas stay identical only if the transport hands every rank the SAME bits.  One all-reduce (MAX of
+        [c, -c]) of a checksum of the current positions; True on every rank iff they all agree."""
+        if self.plan.world == 1 or not self.replicated:
+            return True
+        self.wait()
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            c = self.pos[self._cur_index()].view(torch.int32).to(torch.int64).sum()
+        self.stream.synchronize()
+        ok, _, _ = ranks_agree([int(c.item())], self.group)
+        return ok
+
+    def _cur_index(self) -> int:
+        return 0 if self.sim.pos_buffer(0) == self.pos[0].data_ptr() else 1
 
     # -- stepping ---------------------------------------------------------------
     @property
@@ -346,6 +428,12 @@ class DistributedSimulation:
 
     def step(self, dt: Optional[float] = None) -> None:
         """One sharded step; only enqueues (no host sync)."""
+        if self.comm is not None:
+            t_host = time.perf_counter()
+            self.comm.step(1, dt)
+            self._host_enqueue_s += time.perf_counter() - t_host
+            self._host_steps += 1
+            return
         marks = [] if self._phase_on else None
         t_host = time.perf_counter()
         if self.replicated:
@@ -385,10 +473,19 @@ class DistributedSimulation:
             self._phase_events.append(marks)
 
     def advance(self, nsteps: int, dt: Optional[float] = None) -> None:
+        if self.comm is not None:                 # the library's loop: one foreign call for all the steps
+            t_host = time.perf_counter()
+            self.comm.step(nsteps, dt)
+            self._host_enqueue_s += time.perf_counter() - t_host
+            self._host_steps += nsteps
+            return
         for _ in range(nsteps):
             self.step(dt)
 
     def wait(self) -> None:
+        if self.comm is not None:
+            self.comm.wait()
+            return
         with self.torch.cuda.stream(self.stream):
             if self._pending is not None:
                 self._pending.wait()
@@ -407,6 +504,9 @@ class DistributedSimulation:
         all-gather: local | ag_wait | remote_finish.  When the local items run on the side stream
         (``local_on_side_stream``) their time shows up inside `cross`, which joins them."""
         self.wait()
+        if self.comm is not None:                 # the C loop records no per-phase events: only its host cost is known here
+            return {"host_enqueue": self._host_enqueue_s / max(1, self._host_steps) * 1e3, "steps": self._host_steps,
+                    "driver": "c (nb_comm_step): phases are not timed inside the library's loop"}
         names = (("local", "ag_wait", "cross", "reduce_scatter", "finish") if self.symmetric else
                  ("force", "all_reduce", "finish") if self.replicated else ("local", "ag_wait", "remote_finish"))
         tot = {k: 0.0 for k in names}
@@ -441,6 +541,9 @@ class DistributedSimulation:
 
     def energy(self) -> tuple:
         self.wait()
+        if self.replicated and not self.replicas_identical():
+            raise RuntimeError("the replicas of the all-reduce protocol have diverged: this transport does not deliver "
+                               "bit-identical sums on every rank (use protocol='symmetric' or 'allgather')")
         k, u = self.sim.energy()
         if self.plan.world > 1 and not self.replicated:       # a replicated handle already holds the total
             t = self.torch.tensor([k, u], dtype=self.torch.float64, device=self.device)
@@ -459,6 +562,9 @@ class DistributedSimulation:
     def close(self) -> None:
         if self.sim is not None:
             self.wait()
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
             self.sim.close()
             self.sim = None
         self.pos = []

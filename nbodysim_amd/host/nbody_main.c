@@ -14,6 +14,10 @@
  *              [-no-symmetry] one-sided kernels / all-gather protocol (nb_params.flags)
  *              [-allreduce]  with -shards: the replicated protocol (every handle integrates all n; in-process all-reduce)
  *              [-late-us US] sharded symmetric protocol: local work held back for the side stream (nb_params.sym_late_us)
+ *              [-rccl]       with -shards P: exchange through RCCL instead (nb_comm_create_all + nb_comm_step: collectives on a
+ *                            communication stream per handle, event-ordered, no host sync in the loop); needs one device
+ *                            per shard.  -shards 1 -rccl runs the sharded protocol with ONE rank (NB_FLAG_SHARD_SINGLE):
+ *                            the whole split-step + RCCL path on a one-GPU box
  * -load FILE restarts from a dump: eps, dt, precision, rsqrt mode, sum order, integrator and extras come from its
  * header unless the command line gives them (options are applied in order, so put -load first to override).
  */
@@ -38,7 +42,7 @@ int main(int argc, char **argv)
 {
     size_t n = 65536;
     uint64_t frame0 = 0;
-    int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0;
+    int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0, rccl = 0, shards_given = 0;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
     nb_params p;
@@ -73,32 +77,35 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-allreduce")) p.flags |= NB_FLAG_SHARD_ALLREDUCE;
         else if (!strcmp(argv[i], "-late-us") && i + 1 < argc) p.sym_late_us = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
-        else if (!strcmp(argv[i], "-shards") && i + 1 < argc) shards = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-shards") && i + 1 < argc) { shards = atoi(argv[++i]); shards_given = 1; }
+        else if (!strcmp(argv[i], "-rccl")) rccl = 1;
         else DIE("unknown argument %s", argv[i]);
     }
 
     nb_body *bodies;
     if (reference_ics && !n_given) n = 25000;
+    /* page-locked host memory from the library: nb_sync DMAs straight into it (a malloc'ed array works too, staged) */
     if (load) {
-        bodies = (nb_body *)malloc(n * sizeof *bodies);        /* n <= 0x7fffff00 and consistent with the file: checked by nb_read_header */
-        if (!bodies) DIE("out of memory");
+        bodies = (nb_body *)nb_host_alloc(n * sizeof *bodies); /* n <= 0x7fffff00 and consistent with the file: checked by nb_read_header */
+        if (!bodies) DIE("nb_host_alloc: %s", nb_last_error());
         CHECK(nb_read_bodies(load, bodies, n));
         printf("loaded %zu bodies (frame %llu, eps %g, dt %g, %s%s%s) from %s\n", n, (unsigned long long)frame0, p.eps, p.dt,
                p.precision == NB_FP64 ? "fp64" : "fp32", p.rsqrt_mode == NB_RSQRT_QUAKE ? ", quake" : "",
                p.sum_order == NB_SUM_SEQUENTIAL ? ", sequential" : "", load);
     } else {
-        bodies = (nb_body *)malloc(n * sizeof *bodies);
-        if (!bodies) DIE("out of memory");
+        bodies = (nb_body *)nb_host_alloc(n * sizeof *bodies);
+        if (!bodies) DIE("nb_host_alloc: %s", nb_last_error());
         if (reference_ics) CHECK(nb_default_ics(bodies, n));
         else CHECK(nb_plummer_2d(bodies, n, seed));
     }
 
-    if (shards > 1) {
+    if (shards > 1 || (shards_given && rccl)) {
         /* one process, `shards` handles: each integrates a contiguous block */
-        if (shards > 64 || n % (size_t)shards) DIE("-shards must divide n (and be <= 64)");
+        if (shards < 1 || shards > 64 || n % (size_t)shards) DIE("-shards must divide n (and be 1..64)");
         nb_sim *h[64];
         const int ndev = nb_device_count();
         const size_t blk = n / (size_t)shards;
+        if (shards == 1) p.flags |= NB_FLAG_SHARD_SINGLE;      /* one rank: every pair is local, the collectives are one-rank copies */
         for (int r = 0; r < shards; ++r) {
             nb_params q = p;
             q.i_begin = (uint64_t)r * blk; q.i_count = blk; q.device = ndev > 0 ? r % ndev : 0;
@@ -112,32 +119,47 @@ int main(int argc, char **argv)
         char desc0[1024];
         CHECK(nb_describe(h[0], desc0, sizeof desc0));
         printf("shard 0: %s\n", desc0);
-        const double t0s = now_s();
-        for (int s = 0; s < steps; ++s) {
-            for (int r = 0; r < shards; ++r) CHECK(nb_step_begin(h[r], p.dt));
-            if (symmetric) {                              /* cross-block pairs, then the in-process reduce-scatter */
-                for (int r = 0; r < shards; ++r) CHECK(nb_step_mid(h[r]));
-                CHECK(nb_exchange_accelerations(h, shards));
-            }
-            if (replicated) CHECK(nb_exchange_allreduce(h, shards));
-            for (int r = 0; r < shards; ++r) CHECK(nb_step_finish(h[r]));
-            if (!replicated) CHECK(nb_exchange_positions(h, shards));
+        nb_comm *comm = NULL;
+        if (rccl) {
+            comm = nb_comm_create_all(h, shards);
+            if (!comm) DIE("nb_comm_create_all: %s", nb_last_error());
+            int ver = 0;
+            CHECK(nb_comm_info(comm, NULL, NULL, NULL, &ver));
+            printf("exchange: RCCL %d.%d.%d, one communication stream per handle, event-ordered\n", ver / 10000, ver / 100 % 100, ver % 100);
         }
+        const double t0s = now_s();
+        if (comm) {
+            CHECK(nb_comm_step(comm, p.dt, steps));       /* the whole loop is the library's: INTEGRATION.md 5 shows it */
+        } else {
+            for (int s = 0; s < steps; ++s) {             /* in-process exchange (peer copies / peer reads), also stream-ordered */
+                for (int r = 0; r < shards; ++r) CHECK(nb_step_begin(h[r], p.dt));
+                if (symmetric) {                          /* cross-block pairs, then the in-process reduce-scatter */
+                    for (int r = 0; r < shards; ++r) CHECK(nb_step_mid(h[r]));
+                    CHECK(nb_exchange_accelerations(h, shards));
+                }
+                if (replicated) CHECK(nb_exchange_allreduce(h, shards));
+                for (int r = 0; r < shards; ++r) CHECK(nb_step_finish(h[r]));
+                if (!replicated) CHECK(nb_exchange_positions(h, shards));
+            }
+        }
+        const double t_enq = now_s() - t0s;               /* the host has only enqueued so far */
+        if (comm) CHECK(nb_comm_wait(comm));
+        for (int r = 0; r < shards; ++r) CHECK(nb_wait(h[r]));
         const double pers = (now_s() - t0s) / steps;
         if (replicated) CHECK(nb_sync(h[0], bodies));                 /* every handle holds the whole state */
         else for (int r = 0; r < shards; ++r) CHECK(nb_sync(h[r], bodies + (size_t)r * blk));
         printf("protocol=%s ", symmetric ? "symmetric" : replicated ? "allreduce" : "allgather");
-        printf("shards=%d on %d device(s): frame=%llu  %.3f ms/step  %.3e pair interactions/s\n", shards, ndev,
-               (unsigned long long)nb_frame(h[0]), pers * 1e3, (double)n * (double)n / pers);
+        printf("shards=%d on %d device(s): frame=%llu  %.3f ms/step  %.3e pair interactions/s  host enqueue %.1f us/step\n", shards, ndev,
+               (unsigned long long)nb_frame(h[0]), pers * 1e3, (double)n * (double)n / pers, t_enq / steps * 1e6);
         printf("body[0]: pos=(%.6f, %.6f) vel=(%.6f, %.6f)\n", bodies[0].pos.x, bodies[0].pos.y, bodies[0].vel.x, bodies[0].vel.y);
         if (dump) { CHECK(nb_write_bodies(dump, bodies, n, nb_frame(h[0]), &p)); printf("dumped to %s\n", dump); }
+        if (comm) nb_comm_destroy(comm);
         for (int r = 0; r < shards; ++r) nb_destroy(h[r]);
-        free(bodies);
+        CHECK(nb_host_free(bodies));
         return 0;
     }
     nb_sim *sim = nb_create(bodies, n, &p);
     if (!sim) DIE("nb_create: %s", nb_last_error());
-    const int pinned = nb_host_register(bodies, n * sizeof *bodies) == NB_OK;   /* nb_sync then DMAs into `bodies` */
     char desc[1024];
     CHECK(nb_describe(sim, desc, sizeof desc));
     printf("%s\n", desc);
@@ -171,8 +193,7 @@ int main(int argc, char **argv)
         CHECK(nb_dump(sim, dump));
         printf("dumped to %s\n", dump);
     }
-    if (pinned) nb_host_unregister(bodies);
     nb_destroy(sim);
-    free(bodies);
+    CHECK(nb_host_free(bodies));
     return 0;
 }
