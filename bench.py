@@ -367,7 +367,7 @@ def main() -> None:
 
     # secondary figure, outside the timed region and not part of `value`: the same kernel without the equal-mass
     # specialisation (12 + 2 instead of 10 + 2 instructions per body): what a system with individual masses gets
-    general = general_unscaled = None
+    general = general_unscaled = scaled = None
     if world == 1 and rank == 0 and not args.no_secondary and not args.general_mass and not args.no_kernel_events:
         def secondary(**kw):
             with nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
@@ -380,9 +380,9 @@ def main() -> None:
                 gms, gl = g.profile_read()
                 scaled = "mass_scaled=1" in g.describe()
             return {"avg_launch_ms": gms / gl, "launches": gl, "mass_scaled": scaled}
-        general = secondary()                              # what individual masses get by default (masses folded into the geometry where safe)
-        if general["mass_scaled"]:
-            general_unscaled = secondary(mass_scaling=False)   # the same with the per-pair mass multiplies kept (NB_FLAG_NO_MASS_SCALING)
+        general = secondary()                              # individual masses: both per-pair mass multiplies (12 + 2 per body)
+        general_unscaled = general
+        scaled = secondary(mass_scaling=True)              # opt-in NB_FLAG_MASS_SCALING: masses folded into the pair geometry (11 + 2)
     # second secondary figure: north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of
     # 256 — on the same workload (the symmetric kernel is this repo's faster replacement for it)
     lds_tiled = None
@@ -499,13 +499,13 @@ def main() -> None:
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
                 "general_mass": ({**general, "frac": flop_per_pair * pairs_per_step / (general["avg_launch_ms"] * 1e-3) / 1e12 / peak,
-                                  "note": "same kernel without the equal-mass specialisation (individual masses; mass_scaled = the masses "
-                                          "are folded into the pair geometry, 11 + 2 instructions per body): untimed secondary run"}
+                                  "note": "same kernel without the equal-mass specialisation (individual masses, 12 + 2 instructions per "
+                                          "body): untimed secondary run"}
                                  if general else None),
-                "general_mass_unscaled": ({**general_unscaled,
-                                           "frac": flop_per_pair * pairs_per_step / (general_unscaled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
-                                           "note": "individual masses with both per-pair mass multiplies kept (12 + 2 per body, NB_FLAG_NO_MASS_SCALING)"}
-                                          if general_unscaled else None),
+                "general_mass_scaled": ({**scaled, "frac": flop_per_pair * pairs_per_step / (scaled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
+                                         "note": "opt-in NB_FLAG_MASS_SCALING: masses folded into the pair geometry (11 + 2 per body); off by "
+                                                 "default because it rounds the pair displacement once more (DESIGN.md 4.1)"}
+                                        if scaled else None),
                 "one_sided_lds_tiled": ({**lds_tiled, "kernel": "force_tiled" + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64"),
                                          "frac": flop_per_pair * pairs_per_step / (lds_tiled["avg_launch_ms"] * 1e-3) / 1e12 / peak,
                                          "note": "north_star's kernel design (every ordered pair, j-tiles of 256 in LDS) on the same workload: untimed secondary run"}

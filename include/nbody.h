@@ -104,9 +104,14 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
        NB_FLAG_NO_UNIFORM_MASS = 2,   /* keep the per-pair mass multiply even when all masses are equal */
        NB_FLAG_NO_GUIDED_TAIL  = 4,   /* symmetric planner: uniform work items (no finer items at the end) */
        NB_FLAG_SHARD_ALLREDUCE = 8,   /* with shard_world > 1 and i_count = n: the NB_SHARD_ALLREDUCE protocol below */
-       NB_FLAG_NO_MASS_SCALING = 32,  /* individual masses: keep the per-pair mass multiplies of the symmetric fp32 kernel instead of
-                                         folding the masses into the pair geometry (nb_kernels.hip.h MM_SCALED: one multiply less per
-                                         pair, pair displacements rounded once more: 6e-8 |x| / |d| relative per pair force) */
+       NB_FLAG_MASS_SCALING    = 32,  /* individual masses, fp32, exact rsqrt, tiled sum, eps > 0: fold the masses into the pair
+                                         geometry (nb_kernels.hip.h MM_SCALED: the travelling particle carries m^(-1/2) and its
+                                         pre-multiplied position, one multiply less per pair in the symmetric kernel, none at all
+                                         in the one-sided one).  OFF by default: the pair displacement is then no longer an exact
+                                         difference of two floats (relative error 6e-8 |x| / |d| per pair force), which a broad
+                                         mass spectrum with close heavy pairs turns into 6e-5 of the force scale (measured,
+                                         tests/test_headline_gpu.py) for 2.5 % of kernel time.  Needs m > 0 everywhere and
+                                         m_max^(3/2) / eps^3 inside the float range, else the flag is ignored (nb_describe tells) */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange

@@ -541,13 +541,13 @@ static int do_upload(nb_sim *s, const nb_body *in)
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
-    // Individual masses: the symmetric fp32 kernel can fold them into the pair geometry (MM_SCALED: 11 + 2 instead of
-    // 12 + 2 instructions per body) when every mass is positive and sigma = m^(-1/2), sigma * (the kernels' padding
-    // coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all stay finite floats with room to spare.  Exact rsqrt only:
-    // the Quake mode keeps the reference's arithmetic.  NB_FLAG_NO_MASS_SCALING keeps the 12 + 2 body.
+    // NB_FLAG_MASS_SCALING (opt-in): individual masses folded into the pair geometry (MM_SCALED: 11 + 2 instead of 12 + 2
+    // instructions per body of the symmetric kernel, 8 + 2 instead of 9 + 2 in the one-sided one) when every mass is
+    // positive and sigma = m^(-1/2), sigma * (the kernels' padding coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all
+    // stay finite floats with room to spare.  Exact rsqrt only: the Quake mode keeps the reference's arithmetic.
     s->mass_scaled = false;
     if (!s->uniform_mass && s->p.sum_order == NB_SUM_TILED && !needs_guard(s) && !s->fp64 && !s->dims3 &&
-        s->p.rsqrt_mode == NB_RSQRT_EXACT && !(s->p.flags & NB_FLAG_NO_MASS_SCALING)) {
+        s->p.rsqrt_mode == NB_RSQRT_EXACT && (s->p.flags & NB_FLAG_MASS_SCALING)) {
         double mmin = HUGE_VAL, mmax = 0.0;
         bool finite = true;
         for (size_t i = 0; i < s->n; ++i) {
@@ -611,7 +611,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_NO_MASS_SCALING)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 ||
         (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {

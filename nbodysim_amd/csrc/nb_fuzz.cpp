@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "nb_plan.h"
+#include "nb_sched.h"
 #include "nbody.h"
 
 using namespace nbk;
@@ -190,6 +191,36 @@ static void fuzz_host(const std::string &dir, std::mt19937 &rng)
     ::unlink(path.c_str());
 }
 
+// The sharded step's schedule (nb_sched.cpp): for random protocols / handle counts, every WAIT follows a RECORD of its
+// event on the same handle (this step or, for the all-gather event, the previous one), collectives sit on the
+// communication stream with the right count, and group brackets pair up.
+static void fuzz_schedule(int cases, std::mt19937 &rng)
+{
+    using namespace nbk;
+    for (int c = 0; c < cases; ++c) {
+        const int proto = (int)(rng() % 4), handles = 1 + (int)(rng() % 8);
+        const uint64_t block = 1 + rng() % 100000, full = block * (uint64_t)(1 + rng() % 8);
+        for (int pending = 0; pending < 2; ++pending) {
+            std::vector<nb_comm_op> ops;
+            build_comm_schedule(proto, handles, block, full, pending != 0, ops);
+            std::vector<std::vector<bool>> recorded((size_t)handles, std::vector<bool>(EV_COUNT, false));
+            if (pending) for (auto &r : recorded) r[EV_AG] = true;      // recorded by the previous step
+            int depth = 0;
+            for (const nb_comm_op &o : ops) {
+                if (o.kind == OP_GROUP_START) { REQUIRE(depth == 0 && handles > 1, "group start (protocol %d, %d handles)", proto, handles); ++depth; continue; }
+                if (o.kind == OP_GROUP_END) { --depth; REQUIRE(depth == 0, "group end (protocol %d, %d handles)", proto, handles); continue; }
+                REQUIRE(o.handle >= 0 && o.handle < handles, "handle index (protocol %d, %d handles)", proto, handles);
+                if (o.kind == OP_RECORD) { REQUIRE(o.event >= 0 && o.event < EV_COUNT, "event index (protocol %d, %d handles)", proto, handles); recorded[(size_t)o.handle][(size_t)o.event] = true; }
+                if (o.kind == OP_WAIT) REQUIRE(o.event >= 0 && o.event < EV_COUNT && recorded[(size_t)o.handle][(size_t)o.event], "wait before record (protocol %d, %d handles)", proto, handles);
+                if (o.kind == OP_ALLGATHER || o.kind == OP_REDUCE_SCATTER) REQUIRE(o.stream == ST_COMM && o.count == block, "block collective (protocol %d, %d handles)", proto, handles);
+                if (o.kind == OP_ALLREDUCE) REQUIRE(o.stream == ST_COMM && o.count == full, "all-reduce (protocol %d, %d handles)", proto, handles);
+                if (o.kind <= OP_FINISH) REQUIRE(o.stream == ST_COMPUTE && depth == 0, "compute op (protocol %d, %d handles)", proto, handles);
+            }
+            REQUIRE(depth == 0, "unbalanced group (protocol %d, %d handles)", proto, handles);
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 300;
@@ -198,6 +229,7 @@ int main(int argc, char **argv)
     std::mt19937 rng(seed);
     fuzz_planner(cases, rng);
     fuzz_host(dir, rng);
+    fuzz_schedule(cases, rng);
     std::printf("OK planner_cases=%d seed=%u\n", cases, seed);
     return 0;
 }

@@ -62,7 +62,7 @@ class Simulation:
         shard_allreduce: bool = False,
         first_frame: int = 0,
         shard_single: bool = False,
-        mass_scaling: bool = True,
+        mass_scaling: bool = False,
     ):
         """The last eight arguments are ``nb_params.flags`` and the launch-geometry tuning fields
         (0 / True = the library's automatic choice); the library reads no environment variables."""
@@ -91,7 +91,7 @@ class Simulation:
         p.dims = dims
         p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
                    | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL) | (L.NB_FLAG_SHARD_ALLREDUCE if shard_allreduce else 0)
-                   | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0) | (0 if mass_scaling else L.NB_FLAG_NO_MASS_SCALING))
+                   | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0) | (L.NB_FLAG_MASS_SCALING if mass_scaling else 0))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(BLOCK)
 void force_diag(const float2 *pos, const float *mass, float2 *partial, uint32_t n, uint32_t js, uint32_t i_tiles, float eps2, Stamp *st)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    force_tiled_f32_body<P, RSQ_EXACT, false, UNROLL>(pos, mass, partial, 0, n, 0, n, js, i_tiles, eps2);
+    force_tiled_f32_body<P, RSQ_EXACT, false, UNROLL>(pos, mass, nullptr, partial, 0, n, 0, n, js, i_tiles, eps2);
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
         Stamp s;
@@ -49,7 +49,7 @@ static float time_once(const Ctx &c, uint32_t js, size_t dyn_lds)
     const uint32_t grid = grid_blocks(i_tiles, js);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, c.stream));
-    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS, WS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n, 0xffffffffu, 0u);
+    force_tiled_f32<P, RSQ_EXACT, false, UNROLL, UMASS, WS><<<grid, BLOCK, dyn_lds, c.stream>>>(c.pos, c.mass, nullptr, c.partial, 0, c.n, 0, c.n, js, i_tiles, c.eps2, 1.0f / c.n, 0xffffffffu, 0u);
     CK(hipEventRecord(e1, c.stream));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -3,6 +3,7 @@
 # Ordinary failures continue to the next stage; a stage killed by its timeout stops the run
 # (a hung GPU must not be poked again).
 set -u
+export PYTHONFAULTHANDLER=1   # a process abort (SIGABRT / SIGSEGV) inside the library leaves a Python traceback in the stage's log
 mkdir -p gpurun_out
 stage() {  # stage <seconds> <logfile> <cmd...>
     local secs=$1 log=$2; shift 2
@@ -10,14 +11,16 @@ stage() {  # stage <seconds> <logfile> <cmd...>
     timeout -k 10 "$secs" "$@" > "$log" 2>&1
     local rc=$?
     echo "=== rc=$rc $log" | tee -a gpurun_out/round.log
+    # a failing stage leaves its whole log behind under a name of its own (copy it to profiles/ and commit it)
+    if [ $rc -ne 0 ]; then cp "$log" "gpurun_out/FAILED_$(basename "$log" .log)_$(date -u +%H%M%S).log"; fi
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "stage timed out: stopping" | tee -a gpurun_out/round.log; tail -20 "$log"; exit $rc; fi
     return $rc
 }
 : > gpurun_out/round.log
 for what in "$@"; do
   case $what in
-    tests)  stage 900 gpurun_out/test_gpu.log python -m pytest tests -m gpu -x -q --durations=8; tail -15 gpurun_out/test_gpu.log ;;
-    testsall) stage 1100 gpurun_out/test_gpu.log python -m pytest tests -m gpu -q --durations=12; tail -40 gpurun_out/test_gpu.log ;;
+    tests)  stage 900 gpurun_out/test_gpu.log python -X faulthandler -m pytest tests -m gpu -x -q --durations=8; tail -15 gpurun_out/test_gpu.log ;;
+    testsall) stage 1100 gpurun_out/test_gpu.log python -X faulthandler -m pytest tests -m gpu -q --durations=12; tail -40 gpurun_out/test_gpu.log ;;
     smoke)  stage 300 gpurun_out/smoke.log python -c "import __graft_entry__ as g; g.smoke()"; tail -3 gpurun_out/smoke.log ;;
     bench)  stage 600 gpurun_out/bench.log python bench.py --steps 20 --warmup 3; tail -2 gpurun_out/bench.log ;;
     benchq) stage 300 gpurun_out/bench.log python bench.py --steps 20 --warmup 3 --no-cpu-baseline; tail -2 gpurun_out/bench.log ;;
