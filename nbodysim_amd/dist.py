@@ -311,7 +311,7 @@ class DistributedSimulation:
         assert self.sim.pos_buffer(0) == self.pos[0].data_ptr()
         self.driver = driver
         self.comm = None
-        if driver == "c" and world > 1:
+        if driver == "c":                         # also with one rank: the same code path as on a node (RCCL's one-rank collectives)
             self._create_comm()
 
     def _create_comm(self) -> None:

@@ -269,3 +269,47 @@ def test_allreduce_protocol_over_gloo_matches_single_handle(tmp_path, world, pre
     for r in range(world):
         e = np.load(tmp_path / f"arenergy_{r}.npy")                 # every rank holds the total: no all-reduce of the energy
         assert abs(e[0] - e0) < 1e-9 * abs(e0) and abs(e[1] - e1) < 1e-6 * abs(e1)
+
+
+def _c_driver_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd.dist import DistributedSimulation
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        ic = nb.plummer_2d(32768, 42)
+        sim = DistributedSimulation(ic, eps=0.05, device_index=0, driver="c")
+        assert sim.driver == "c" and sim.comm is not None and sim.comm.info()["world"] == 1
+        k0, u0 = sim.energy()
+        sim.advance(4, 1e-3)            # ONE foreign call: nb_comm_step(comm, dt, 4)
+        sim.step(1e-3)
+        k1, u1 = sim.energy()
+        rep = sim.phase_report()
+        assert rep["steps"] == 5 and rep["host_enqueue"] > 0 and "driver" in rep
+        mine = sim.sync().copy()
+        assert sim.frame == 5
+        np.save(Path(out_dir) / "pos.npy", mine["pos"])
+        np.save(Path(out_dir) / "energy.npy", np.array([k0, u0, k1, u1]))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c_driver_of_the_sharded_simulation_one_rank(tmp_path):
+    """dist.py with driver="c": the RCCL id broadcast through the torch process group, nb_comm_create_rank, the whole
+    loop in nb_comm_step — with the one rank a one-GPU box allows — against the plain handle, bit for bit."""
+    import torch.multiprocessing as mp
+    mp.spawn(_c_driver_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    pos, _, (k0, u0, k1, u1) = _reference(32768, 5, "fp32")
+    got = np.load(tmp_path / "pos.npy")
+    assert np.array_equal(got.view(np.uint32), pos.view(np.uint32))
+    e = np.load(tmp_path / "energy.npy")
+    assert abs(e[0] + e[1] - k0 - u0) < 1e-12 * abs(k0 + u0) and abs(e[2] + e[3] - k1 - u1) < 1e-12 * abs(k1 + u1)

@@ -40,7 +40,7 @@ for what in "$@"; do
                        "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS" \
                        "GRBM_GUI_ACTIVE GRBM_COUNT FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
               tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-              stage 300 gpurun_out/pmc_$tag.log rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events ${PMC_ARGS:-}
+              stage 300 gpurun_out/pmc_$tag.log rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sustained ${PMC_ARGS:-}
             done
             find gpurun_out/pmc -name '*counter_collection.csv' | head ;;
     *) echo "unknown stage $what" ;;
