@@ -287,6 +287,7 @@ static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t worl
     t.late_units = sharded ? late_units_for(p, fp64, cus, world) : 0u;
     t.wg_per_cu = sharded ? 24u : 0u;             // reduce-scatter protocol: two launches per step (nb_plan.cpp)
     t.late_chunks = fp64 ? 1u : 2u;
+    t.even_chunks = !fp64 && p.dims != 3;         // the fp32 2-D symmetric kernel sweeps chunk pairs (sym_chunks2)
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
         for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k];

@@ -410,8 +410,15 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 #ifndef NB_SYM_P
 #define NB_SYM_P 4
 #endif
+#ifndef NB_SYM_TQ
+#define NB_SYM_TQ 2          // travelling particles per lane (1: one 64-particle chunk at a time; 2: chunk PAIRS, see sym_chunks2)
+#endif
+#ifndef NB_SYM_UNROLL2
+#define NB_SYM_UNROLL2 1     // rotation steps unrolled together in sym_chunks2 (8 bodies per step already)
+#endif
 constexpr int SYM_P = NB_SYM_P;                          // packed stationary pairs per lane
 constexpr int SYM_UNROLL = NB_SYM_UNROLL;
+constexpr int SYM_UNROLL2 = NB_SYM_UNROLL2;
 constexpr uint32_t SYM_WT = 64 * 2 * SYM_P;              // stationary particles per wave  (512)
 static_assert(4 * SYM_WT == SYM_SB, "block-tile of the planner (nb_plan.h) = 4 waves x 64 lanes x 2 SYM_P particles");
 
@@ -546,6 +553,125 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
     }
 }
 
+// sym_chunks2 — the same sweep with TWO travelling particles per lane (a PAIR of 64-particle chunks, c and c + 1, at a
+// time).  The packed halves now hold the two travelling particles (q0, q1) and the stationary particle is the operand
+// broadcast into both halves (op_sel: free), where sym_chunks packs two stationary particles against one broadcast
+// travelling particle.  Same 10 + 2 (12 + 2) instructions per four ordered interactions, but
+//   * one rotation step serves 16 pairs per lane instead of 8 with 8 instead of 6 ds_bpermute_b32 (x, y and the two
+//     accumulator components of TWO particles ride in four register pairs): a third fewer rotations per pair, and twice
+//     the VALU work between two dependent hops of the accumulators through the LDS crossbar;
+//   * the travelling accumulators need no half-summing, and the 4-wave combine + barrier happens once per chunk pair.
+// The stationary accumulators become per-particle pairs {from q0, from q1} (32 registers instead of 16), summed at the
+// end.  An odd chunk count leaves the second half of the last pair empty (PAD particles: half of that pair's work is
+// wasted), so the planner cuts items into even chunk counts for handles that run this kernel (SymTuning::even_chunks).
+template <int RSQ, int MM, bool DIAG>
+__device__ __forceinline__
+void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
+                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                 const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&mi)[SYM_P],
+                 v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], float eps2, float um_mass, float4 (*red)[4][64])
+{
+    static_assert(MM != MM_SCALED, "the mass-scaled body keeps the one-chunk form");
+    constexpr bool UM = MM == MM_UNIFORM;
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    const v2f e2 = {eps2, eps2};
+    v2f bx[2 * SYM_P], by[2 * SYM_P];                  // stationary particle s = 2p + h: {partial from q0, partial from q1}
+#pragma unroll
+    for (int k = 0; k < 2 * SYM_P; ++k) { bx[k] = (v2f){0.f, 0.f}; by[k] = (v2f){0.f, 0.f}; }
+
+    auto fetch = [&](uint32_t c, v2f &x, v2f &y, v2f &m) {          // chunks c and c + 1 of the item (if inside it)
+        x = (v2f){PAD_XY, PAD_XY}; y = x; m = (v2f){0.f, 0.f};
+        if (c < cnt) {
+            const uint32_t j = (c0 + c) * SYM_CH + lane;
+            if (j < n) { const float2 pj = pos[j]; x.x = pj.x; y.x = pj.y; if constexpr (!UM) m.x = mass[j]; }
+        }
+        if (c + 1 < cnt) {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (j < n) { const float2 pj = pos[j]; x.y = pj.x; y.y = pj.y; if constexpr (!UM) m.y = mass[j]; }
+        }
+    };
+    v2f xq, yq, mq;
+    fetch(0, xq, yq, mq);
+    for (uint32_t c = 0; c < cnt; c += 2) {
+        v2f xn, yn, mn;
+        fetch(c + 2, xn, yn, mn);                      // next pair in flight behind the 64 steps
+        v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};         // {q0, q1}
+#pragma unroll SYM_UNROLL2
+        for (int step = 0; step < 64; ++step) {
+            const v2f xr = {lane_rot(xq.x, addr), lane_rot(xq.y, addr)};
+            const v2f yr = {lane_rot(yq.x, addr), lane_rot(yq.y, addr)};
+            v2f mr = {0.f, 0.f};
+            if constexpr (!UM) mr = (v2f){lane_rot(mq.x, addr), lane_rot(mq.y, addr)};
+#pragma unroll
+            for (int p = 0; p < SYM_P; ++p) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs = h ? xi[p].y : xi[p].x, ys = h ? yi[p].y : yi[p].x;
+                    const v2f dx = xq - (v2f){xs, xs};
+                    const v2f dy = yq - (v2f){ys, ys};
+                    v2f r2 = __builtin_elementwise_fma(dx, dx, e2);
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    v2f inv;
+                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else inv = quake_rsqrt2(r2);
+                    const v2f inv3 = inv * (inv * inv);
+                    if constexpr (UM) {
+                        bx[2 * p + h] = __builtin_elementwise_fma(inv3, dx, bx[2 * p + h]);
+                        by[2 * p + h] = __builtin_elementwise_fma(inv3, dy, by[2 * p + h]);
+                        if constexpr (!DIAG) {
+                            aqx = __builtin_elementwise_fma(-inv3, dx, aqx);
+                            aqy = __builtin_elementwise_fma(-inv3, dy, aqy);
+                        }
+                    } else {
+                        const v2f si = mq * inv3;                          // force ON the stationary particle: m_q / r^3 per half
+                        bx[2 * p + h] = __builtin_elementwise_fma(si, dx, bx[2 * p + h]);
+                        by[2 * p + h] = __builtin_elementwise_fma(si, dy, by[2 * p + h]);
+                        if constexpr (!DIAG) {
+                            const float ms = h ? mi[p].y : mi[p].x;
+                            const v2f sj = (v2f){ms, ms} * inv3;           // force ON the travelling pair: m_s / r^3
+                            aqx = __builtin_elementwise_fma(-sj, dx, aqx);
+                            aqy = __builtin_elementwise_fma(-sj, dy, aqy);
+                        }
+                    }
+                }
+            }
+            xq = xr; yq = yr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) {
+                aqx = (v2f){lane_rot(aqx.x, addr), lane_rot(aqx.y, addr)};
+                aqy = (v2f){lane_rot(aqy.x, addr), lane_rot(aqy.y, addr)};
+            }
+        }
+        if constexpr (!DIAG) {
+            // lane l holds the accumulators of travelling particles (chunk c, l) and (chunk c + 1, l): combine the 4 waves
+            // in wave order; wave 0 stores chunk c, wave 1 chunk c + 1
+            float4 r = make_float4(aqx.x, aqy.x, aqx.y, aqy.y);
+            if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; r.z *= um_mass; r.w *= um_mass; }
+            float4 (*rb)[64] = red[(c >> 1) & 1u];
+            rb[w][lane] = r;
+            __syncthreads();
+            if (w < 2 && c + w < cnt) {
+                const uint32_t j = (c0 + c + w) * SYM_CH + lane;
+                float2 a = w ? make_float2(rb[0][lane].z, rb[0][lane].w) : make_float2(rb[0][lane].x, rb[0][lane].y);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    a.x += w ? rb[k][lane].z : rb[k][lane].x;
+                    a.y += w ? rb[k][lane].w : rb[k][lane].y;
+                }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn;
+        if constexpr (!UM) mq = mn;
+    }
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        ax[p] += (v2f){bx[2 * p].x + bx[2 * p].y, bx[2 * p + 1].x + bx[2 * p + 1].y};
+        ay[p] += (v2f){by[2 * p].x + by[2 * p].y, by[2 * p + 1].x + by[2 * p + 1].y};
+    }
+}
+
 template <int RSQ, int MM>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
 void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
@@ -554,7 +680,9 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
                    uint32_t n, float eps2, float um_mass)
 {
     constexpr bool UM = MM == MM_UNIFORM;
-    __shared__ float2 red[2][4][64];
+    constexpr bool PAIRS = NB_SYM_TQ == 2 && MM != MM_SCALED;     // chunk pairs (sym_chunks2)
+    __shared__ float4 red4[2][4][64];
+    float2 (*red)[4][64] = reinterpret_cast<float2 (*)[4][64]>(red4);
     const SymItem it = items[blockIdx.x];
     const bool diag = it.diag != 0;
     const uint32_t s_row = it.s_row;
@@ -575,8 +703,13 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
-    if (diag) sym_chunks<RSQ, MM, true>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
-    else      sym_chunks<RSQ, MM, false>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    if constexpr (PAIRS) {
+        if (diag) sym_chunks2<RSQ, MM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red4);
+        else      sym_chunks2<RSQ, MM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red4);
+    } else {
+        if (diag) sym_chunks<RSQ, MM, true>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        else      sym_chunks<RSQ, MM, false>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+    }
 
     float2 *__restrict__ out = slab_s + (size_t)s_row * SYM_SB;
 #pragma unroll

@@ -95,6 +95,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         L = fill > grain ? fill : grain;
     }
     if (L < 1) L = 1;
+    if (tune.even_chunks && !tune.forced_L) L = (L + 1u) & ~1u;      // chunk pairs (a forced L is taken as given)
 
     // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
     std::vector<SymItem> local_items, cross_items, late_items;
@@ -159,7 +160,8 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
             for (const auto &it : list) {
                 const double f = total ? (double)done / (double)total : 0.0;
                 const uint32_t div = f < tune.tail_at[0] ? 1u : f < tune.tail_at[1] ? 2u : f < tune.tail_at[2] ? 4u : 8u;
-                const uint32_t piece = (L + div - 1) / div;
+                uint32_t piece = (L + div - 1) / div;
+                if (tune.even_chunks) piece = (piece + 1u) & ~1u;
                 done += it.cnt;
                 if (div == 1 || it.cnt <= piece) { out.push_back(it); continue; }
                 --rows_of[it.tile];

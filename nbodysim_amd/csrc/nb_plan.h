@@ -42,6 +42,8 @@ struct SymTuning {
     uint32_t late_units = 0;      // chunk-units of local work held back for the side stream (sharded ranks)
     uint32_t late_chunks = 2;     // chunks per late item
     bool guided_tail = true;      // finer items at the end of each launch
+    bool even_chunks = false;     // cut items into EVEN chunk counts: the fp32 2-D kernel sweeps chunk PAIRS (sym_chunks2), and
+                                  // an odd item wastes half a pair
     double tail_at[3] = {0.85, 0.94, 0.98};
 };
 
