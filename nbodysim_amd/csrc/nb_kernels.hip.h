@@ -411,7 +411,7 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 #define NB_SYM_P 4
 #endif
 #ifndef NB_SYM_TQ
-#define NB_SYM_TQ 2          // travelling particles per lane (1: one 64-particle chunk at a time; 2: chunk PAIRS, see sym_chunks2)
+#define NB_SYM_TQ 1          // travelling particles per lane (1: one 64-particle chunk at a time; 2: chunk PAIRS, see sym_chunks2)
 #endif
 #ifndef NB_SYM_UNROLL2
 #define NB_SYM_UNROLL2 1     // rotation steps unrolled together in sym_chunks2 (8 bodies per step already)
