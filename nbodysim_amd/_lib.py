@@ -86,7 +86,7 @@ class nb_params(C.Structure):
         ("sym_late_us", C.c_float),
         ("lanes_p", C.c_int32),
         ("sym_tail", C.c_float * 3),
-        ("reserved1", C.c_int32),
+        ("sym_chunk_pairs", C.c_int32),
         ("first_frame", C.c_uint64),
     ]
 

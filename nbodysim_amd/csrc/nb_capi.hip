@@ -93,6 +93,7 @@ struct nb_sim {
     bool acc_valid = false;         // KDK: acc holds a(x_cur)
     bool uniform_mass = false;      // every body has the same mass: the per-pair mass multiply is hoisted
     float um_mass = 0.f;
+    bool sym_pairs = false;         // symmetric fp32 kernel sweeps chunk pairs (want_pairs)
     bool mass_scaled = false;       // individual masses folded into the pair geometry (MM_SCALED, nb_kernels.hip.h)
     float *sigma = nullptr;         // m^(-1/2) per particle, for mass_scaled
 
@@ -280,14 +281,25 @@ static uint32_t late_units_for(const nb_params &p, bool fp64, int cus, uint32_t 
     return (uint32_t)(us * (fp64 ? 14.0 : 35.0) * (double)cus / 256.0);
 }
 
-static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t world, bool sharded)
+// Chunk PAIRS (sym_chunks2: two travelling particles per lane) pay from ~65 536 bodies on (-2 ... -3 % at 131 072 - 262 144,
+// neutral at 65 536; below that the coarser items and the lower occupancy — 146-158 VGPRs, 3 waves per SIMD — cost more
+// than the saved rotations: profiles/r03_chunk_pairs_sweep.log).  fp32 2-D only.  nb_params.sym_chunk_pairs = 1 / -1 forces it.
+// Rank-independent (n and parameters only): it shapes the plan every rank must agree on.
+static bool want_pairs(const nb_params &p, size_t n)
+{
+    if (p.precision == NB_FP64 || p.dims == 3) return false;
+    if (p.sym_chunk_pairs) return p.sym_chunk_pairs > 0;
+    return n >= 65536;
+}
+
+static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t world, bool sharded, size_t n)
 {
     SymTuning t;
     t.forced_L = p.sym_chunks_per_item > 0 ? (uint32_t)p.sym_chunks_per_item : 0u;
     t.late_units = sharded ? late_units_for(p, fp64, cus, world) : 0u;
     t.wg_per_cu = sharded ? 24u : 0u;             // reduce-scatter protocol: two launches per step (nb_plan.cpp)
     t.late_chunks = fp64 ? 1u : 2u;
-    t.even_chunks = !fp64 && p.dims != 3;         // the fp32 2-D symmetric kernel sweeps chunk pairs (sym_chunks2)
+    t.even_chunks = want_pairs(p, n);            // the kernel sweeps chunk pairs: even chunk counts
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
         for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k];
@@ -328,7 +340,7 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
     if (tuning) p = *tuning; else nb_params_default(&p);
     const bool fp64 = p.precision == NB_FP64;
     SymPlan pl;
-    build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, tuning_of(p, fp64, cus, (uint32_t)world, world > 1), pl);
+    build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, tuning_of(p, fp64, cus, (uint32_t)world, world > 1, n), pl);
     if (info) fill_sym_info(pl, (uint32_t)n, (uint32_t)world, cus, fp64 ? 16 : 8, true, info);
     if (items_out) memcpy(items_out, pl.items.data(), (pl.items.size() < cap ? pl.items.size() : cap) * sizeof(SymItem));
     return NB_OK;
@@ -458,7 +470,8 @@ static int plan_sym(nb_sim *s)
     const uint32_t world = split ? (uint32_t)s->p.shard_world : 1u;
     const uint32_t rank = split ? (uint32_t)s->p.shard_rank : 0u;
     SymPlan pl;
-    build_sym_plan(n, (uint32_t)s->cus, rank, world, tuning_of(s->p, s->fp64, s->cus, world, s->sym_sharded), pl);   // late items: sharded only
+    build_sym_plan(n, (uint32_t)s->cus, rank, world, tuning_of(s->p, s->fp64, s->cus, world, s->sym_sharded, s->n), pl);   // late items: sharded only
+    s->sym_pairs = want_pairs(s->p, s->n);
     const uint32_t tiles = pl.tiles, row = pl.rowbase[tiles];
     s->sym_info.struct_size = (uint32_t)sizeof(nb_sym_info);
     fill_sym_info(pl, n, world, s->cus, s->esz, true, &s->sym_info);
@@ -614,7 +627,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     }
     if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
-    if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 ||
+    if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {
         nb_set_error("nb_create: tuning field out of range (sym_chunks_per_item >= 0, sym_aux_stream in -1..1, lanes_p in {0,1,2,4}, j_slices >= 0)");
         return nullptr;
@@ -824,15 +837,18 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         const float *mass = (const float *)s->mass;
         float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
         const float *sg = s->sigma;
+#define NB_SYM_LAUNCH(RQ, MMODE, PR, UMV) force_sym_f32<RQ, MMODE, PR><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV)
+        const bool pairs = s->sym_pairs && !s->mass_scaled;          // chunk pairs (sym_chunks2): large systems, see want_pairs
         if (s->uniform_mass) {
-            if (quake) force_sym_f32<RSQ_QUAKE, MM_UNIFORM><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, s->um_mass);
-            else       force_sym_f32<RSQ_EXACT, MM_UNIFORM><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, s->um_mass);
+            if (quake) { if (pairs) NB_SYM_LAUNCH(RSQ_QUAKE, MM_UNIFORM, true, s->um_mass); else NB_SYM_LAUNCH(RSQ_QUAKE, MM_UNIFORM, false, s->um_mass); }
+            else       { if (pairs) NB_SYM_LAUNCH(RSQ_EXACT, MM_UNIFORM, true, s->um_mass); else NB_SYM_LAUNCH(RSQ_EXACT, MM_UNIFORM, false, s->um_mass); }
         } else if (s->mass_scaled) {                 // exact rsqrt only (decided at upload)
-            force_sym_f32<RSQ_EXACT, MM_SCALED><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
+            NB_SYM_LAUNCH(RSQ_EXACT, MM_SCALED, false, 1.0f);
         } else {
-            if (quake) force_sym_f32<RSQ_QUAKE, MM_GENERAL><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
-            else       force_sym_f32<RSQ_EXACT, MM_GENERAL><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, 1.0f);
+            if (quake) { if (pairs) NB_SYM_LAUNCH(RSQ_QUAKE, MM_GENERAL, true, 1.0f); else NB_SYM_LAUNCH(RSQ_QUAKE, MM_GENERAL, false, 1.0f); }
+            else       { if (pairs) NB_SYM_LAUNCH(RSQ_EXACT, MM_GENERAL, true, 1.0f); else NB_SYM_LAUNCH(RSQ_EXACT, MM_GENERAL, false, 1.0f); }
         }
+#undef NB_SYM_LAUNCH
     }
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr, st)) return NB_EHIP;
@@ -1701,13 +1717,13 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
-             (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_items, s->sym_L, s->sym_items_late,
+             (int)(s->sym || s->sym_sharded || s->sym_replicated), (int)(s->sym_pairs && !s->mass_scaled), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;
 }

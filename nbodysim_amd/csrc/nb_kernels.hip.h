@@ -410,11 +410,8 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 #ifndef NB_SYM_P
 #define NB_SYM_P 4
 #endif
-#ifndef NB_SYM_TQ
-#define NB_SYM_TQ 1          // travelling particles per lane (1: one 64-particle chunk at a time; 2: chunk PAIRS, see sym_chunks2)
-#endif
 #ifndef NB_SYM_UNROLL2
-#define NB_SYM_UNROLL2 1     // rotation steps unrolled together in sym_chunks2 (8 bodies per step already)
+#define NB_SYM_UNROLL2 2     // rotation steps unrolled together in sym_chunks2 (removes the register copies of the rotation: -1.4 %)
 #endif
 constexpr int SYM_P = NB_SYM_P;                          // packed stationary pairs per lane
 constexpr int SYM_UNROLL = NB_SYM_UNROLL;
@@ -672,7 +669,7 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
     }
 }
 
-template <int RSQ, int MM>
+template <int RSQ, int MM, bool PAIRS = false>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
 void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                    const SymItem *__restrict__ items,
@@ -680,7 +677,7 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
                    uint32_t n, float eps2, float um_mass)
 {
     constexpr bool UM = MM == MM_UNIFORM;
-    constexpr bool PAIRS = NB_SYM_TQ == 2 && MM != MM_SCALED;     // chunk pairs (sym_chunks2)
+    static_assert(!(PAIRS && MM == MM_SCALED), "the mass-scaled body keeps the one-chunk form");
     __shared__ float4 red4[2][4][64];
     float2 (*red)[4][64] = reinterpret_cast<float2 (*)[4][64]>(red4);
     const SymItem it = items[blockIdx.x];

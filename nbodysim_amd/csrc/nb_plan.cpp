@@ -95,7 +95,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         L = fill > grain ? fill : grain;
     }
     if (L < 1) L = 1;
-    if (tune.even_chunks && !tune.forced_L) L = (L + 1u) & ~1u;      // chunk pairs (a forced L is taken as given)
+    if (tune.even_chunks && !tune.forced_L) L = L < 2 ? 2u : (L & ~1u);   // chunk pairs (a forced L is taken as given)
 
     // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
     std::vector<SymItem> local_items, cross_items, late_items;

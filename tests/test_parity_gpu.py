@@ -238,18 +238,23 @@ def test_uniform_mass_fast_path_matches_general_path(nbo):
 @pytest.mark.parametrize("n", [16384, 20000, 70001])
 @pytest.mark.parametrize("masses", ["uniform", "individual"])
 @pytest.mark.parametrize("rsqrt", ["exact", "quake"])
-def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt):
+@pytest.mark.parametrize("pairs,chunks", [(-1, 0), (1, 0), (1, 3)])
+def test_symmetric_kernel_matches_one_sided_and_fp64(nbo, n, masses, rsqrt, pairs, chunks):
     """force_sym_f32 evaluates each unordered pair once (Newton's third law); it must agree with
     the one-sided kernel and with the fp64 direct sum on the global force scale, and conserve
-    momentum better than the one-sided sum (its pair forces are exactly opposite)."""
+    momentum better than the one-sided sum (its pair forces are exactly opposite).  Both forms of the sweep: one
+    travelling chunk at a time (sym_chunk_pairs = -1) and chunk pairs (+1) — the latter also with items of THREE chunks,
+    whose second pair is half empty."""
     ic = nb.plummer_2d(n, 5)
     if masses == "individual":
         rng = np.random.default_rng(n)
         ic["mass"] = (rng.uniform(0.5, 1.5, n) / n).astype(np.float32)
     res = {}
     for tag, symm in (("sym", True), ("one_sided", False)):
-        with nb.Simulation(ic, eps=0.02, rsqrt=rsqrt, symmetry=symm) as sim:
+        with nb.Simulation(ic, eps=0.02, rsqrt=rsqrt, symmetry=symm, sym_chunk_pairs=pairs, sym_chunks_per_item=chunks) as sim:
             assert f"symmetric={int(symm)}" in sim.describe()
+            if symm:
+                assert f"chunk_pairs={int(pairs > 0)}" in sim.describe() and (chunks == 0 or f"chunks/item={chunks}" in sim.describe())
             res[tag] = sim.accelerations().astype(np.float64)
     scale = np.max(np.abs(res["one_sided"]))
     assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
