@@ -356,8 +356,10 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
 // Why so strict: hipHostRegister / the runtime's own pinning of pageable copy sources work on whole
 // PAGES; a malloc'ed array shares its first and last page with whatever the heap put next to it, and a registration
 // that outlives the array (a std::vector that reallocated) keeps pinning pages that now belong to someone else.
-// Round 2 saw one process abort inside nb_upload right after nb_host_register of an unaligned numpy array; the
-// constructions of tools/pin_probe.hip (profiles/r03_pin_probe.log) show what the runtime does in each case.
+// Round 2 saw one process abort inside nb_upload right after nb_host_register of an unaligned numpy array.  CAUSE
+// UNKNOWN: no log of that run exists, and none of the nine deterministic constructions of tools/pin_probe.hip (shared
+// pages, overlapping registrations, freed-while-registered memory reused at the same address ...) aborts on this
+// runtime (profiles/r03_pin_probe.log).  The rules above are therefore a DEFENSIVE change, not the fix of a known bug.
 struct PinnedRange { uintptr_t lo, hi; bool owned; };
 static std::mutex g_pin_mutex;
 static std::vector<PinnedRange> g_pinned;
