@@ -168,6 +168,31 @@ def test_no_cpu_fallback_without_device():
     assert e.value.code == L.NB_ENODEVICE and lib.nb_last_error_code() == L.NB_ENODEVICE   # a NULL handle still says why
 
 
+def test_host_memory_and_comm_entry_points_without_a_device():
+    """The page-locked-memory and communicator entry points check their arguments first and fail loudly without a GPU
+    (no silent pageable fallback behind nb_host_alloc, no other transport behind nb_comm_*)."""
+    import mmap
+    lib = nb.load()
+    if lib.nb_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu suite")
+    b = nb.bodies_array(1000)
+    odd = b[1:]                                                  # 64 bytes into the array: not page-aligned
+    assert lib.nb_host_register(odd.ctypes.data, odd.nbytes) == L.NB_EINVAL and b"whole number" in lib.nb_last_error()
+    assert lib.nb_host_register(None, 4096) == L.NB_EINVAL
+    assert lib.nb_host_unregister(b.ctypes.data) == L.NB_EINVAL and lib.nb_host_free(b.ctypes.data) == L.NB_EINVAL
+    m = mmap.mmap(-1, 2 * mmap.PAGESIZE)
+    addr = C.addressof(C.c_char.from_buffer(m))
+    assert lib.nb_host_register(addr, 2 * mmap.PAGESIZE) == L.NB_EHIP            # whole pages, but no device to pin them for
+    assert lib.nb_host_alloc(4096) is None and lib.nb_last_error_code() == L.NB_ENODEVICE
+    assert lib.nb_host_free(None) == L.NB_OK
+    p3 = (C.c_double * 3)()
+    assert lib.nb_momentum(None, p3, None) == L.NB_EINVAL
+    assert lib.nb_element_layout(None, None, None) == L.NB_EINVAL and lib.nb_device(None) == -1
+    assert lib.nb_comm_create_rank(None, None, 0, 1) is None and lib.nb_last_error_code() == L.NB_EINVAL
+    assert lib.nb_comm_flush(None) == L.NB_EINVAL and lib.nb_comm_info(None, None, None, None, None) == L.NB_EINVAL
+    lib.nb_comm_destroy(None)                                    # no-op
+
+
 def test_product_does_not_reference_oracle():
     """The product path may not import, link or call anything under oracle/."""
     for p in list((ROOT / "nbodysim_amd").rglob("*.py")) + list((ROOT / "nbodysim_amd" / "csrc").glob("*")) + \
