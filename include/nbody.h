@@ -346,7 +346,11 @@ int   nb_shard_rank(const nb_sim *s, int *world);   /* nb_params.shard_rank (and
  * Handles: created with shard_rank / shard_world, rank r owning the block [r n/world, +n/world) (equal blocks, which
  * the in-place all-gather and the reduce-scatter need), or all n particles for NB_SHARD_ALLREDUCE; an unsharded
  * handle forms a communicator of one rank (its all-gather is RCCL's one-rank no-op).  RCCL is loaded at first use
- * (librccl.so.1); without it nb_comm_create_* fail with NB_ENODEVICE — there is no other transport behind this API. */
+ * (librccl.so.1); without it nb_comm_create_* fail with NB_ENODEVICE — there is no other transport behind this API.
+ * Like a handle, an nb_comm is driven by ONE thread, and its handles must outlive it (nb_comm_destroy first).  Between
+ * nb_comm_step calls the handles may be read (nb_comm_flush, then nb_sync / nb_energy / nb_momentum) but not stepped by
+ * other means.  If a call fails half-way through a step (a HIP or RCCL error), the run cannot be continued: destroy the
+ * communicator and the handles. */
 typedef struct nb_comm nb_comm;
 #define NB_COMM_ID_BYTES 128
 int      nb_comm_unique_id(void *id_out /* NB_COMM_ID_BYTES */);
