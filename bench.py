@@ -139,9 +139,9 @@ class DeviceSampler:
         # what limited the clock, from the samples themselves
         if cap and fq:
             near_cap = out["power_w_max"] >= 0.93 * cap
-            out["clock_limit"] = ("socket power at its cap: power-limited" if near_cap else
-                                  f"power stayed below the cap ({out['power_w_max']:.0f} of {cap:.0f} W) at {out['sclk_mhz_mean']:.0f} MHz mean: "
-                                  "the clock was NOT power-limited on this box (thermal / voltage-frequency limit of the part)")
+            out["clock_limit"] = ("socket power reached its cap during the region: power-limited" if near_cap else
+                                  f"socket power peaked at {out['power_w_max']:.0f} W of a {cap:.0f} W cap with the clock at {out['sclk_mhz_mean']:.0f} MHz "
+                                  "mean: the cap was not what held the clock on this box (these samples do not say what did)")
         return out
 
 
