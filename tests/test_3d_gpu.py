@@ -69,6 +69,18 @@ def test_3d_symmetric_equals_one_sided_and_momentum_is_conserved():
     assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
     m = ic["mass"].astype(np.float64)[:, None]
     assert np.abs((m * res["sym"]).sum(0)).max() < 1e-6 * np.abs(m * res["sym"]).sum(0).max()
+    # nb_momentum in 3-D (mass rides in pos.w on the device): fp32 and fp64 handles against the host sum, before and after steps
+    for precision in ("fp32", "fp64"):
+        with nb.Simulation(ic, eps=0.02, dims=3, precision=precision) as sim:
+            (px, py, pz), lz = sim.momentum()
+            want = (m * ic["vel"].astype(np.float64)).sum(0)
+            lz0 = float((m[:, 0] * (ic["pos"][:, 0].astype(np.float64) * ic["vel"][:, 1] - ic["pos"][:, 1].astype(np.float64) * ic["vel"][:, 0])).sum())
+            assert np.allclose([px, py, pz], want, rtol=0, atol=1e-12) and abs(lz - lz0) < 1e-12
+            sim.advance(20, 1e-3)
+            (qx, qy, qz), lz1 = sim.momentum()
+            pscale = np.abs(m * ic["vel"]).sum(0).max()
+            assert max(abs(qx - px), abs(qy - py), abs(qz - pz)) < 1e-5 * pscale and abs(lz1 - lz) < 1e-5 * abs(np.abs(m[:, 0] * np.linalg.norm(ic["pos"][:, :2], axis=1)
+                                                                                                                   * np.linalg.norm(ic["vel"][:, :2], axis=1)).sum())
 
 
 def test_3d_dump_keeps_z_and_2d_dump_zeroes_padding(tmp_path):
