@@ -97,10 +97,16 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     if (L < 1) L = 1;
     if (tune.even_chunks && !tune.forced_L) L = L < 2 ? 2u : (L & ~1u);   // chunk pairs (a forced L is taken as given)
 
-    // the cross items of ALL ranks in order, to find this rank's run: item k goes to rank floor(start_k * world / total)
+    // Cross items: EVERY tile's range of later-block chunks [be, chunks) is cut into `world` contiguous sub-ranges and
+    // rank r takes sub-range (r + I) mod world of tile I.  Every rank therefore holds a slice of every tile: its stationary
+    // rows and travelling segments — and with them the work of its sym_gather — are spread over all tiles instead of
+    // piling up on the few tiles a contiguous run of the tile-major item list covers (round 2: a rank's gather ran at
+    // 1.7 TB/s on ~20 heavy tiles; profiles/r03_shard_p8_*).  The sub-ranges of a tile partition [be, chunks) exactly, so
+    // all ranks together still meet every (tile, chunk) pair once; shares differ by at most one unit per tile, rotated
+    // over the ranks.  Units are chunk pairs for handles that sweep pairs (even_chunks).
     std::vector<SymItem> local_items, cross_items, late_items;
     std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0), late_rows_of(tiles, 0);
-    uint64_t cum = 0;
+    const uint32_t unit = tune.even_chunks ? 2u : 1u;
     for (uint32_t I = 0; I < tiles; ++I) {
         const uint32_t be = g.block_end_chunk(I);
         if (g.block_of(I) == rank || world == 1) {
@@ -114,14 +120,15 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
                 ++local_rows_of[I];
             }
         }
-        for (uint32_t c = be; c < chunks; c += L) {                                 // later blocks
-            const uint32_t cnt = chunks - c < L ? chunks - c : L;
-            const uint32_t owner = cross_total ? (uint32_t)((cum * world) / cross_total) : 0u;
-            if (owner == rank) {
-                cross_items.push_back(SymItem{I, c, cnt, 0u, 0, 0u, 1u});
+        if (be < chunks) {                                                          // later blocks: this rank's slice
+            const uint64_t len_u = (chunks - be) / unit;                            // whole units; a leftover odd chunk joins the last slice
+            const uint32_t slot = (rank + I) % world;
+            const uint32_t lo = be + unit * (uint32_t)(len_u * slot / world);
+            const uint32_t hi = slot + 1 == world ? chunks : be + unit * (uint32_t)(len_u * (slot + 1) / world);
+            for (uint32_t c = lo; c < hi; c += L) {
+                cross_items.push_back(SymItem{I, c, hi - c < L ? hi - c : L, 0u, 0, 0u, 1u});
                 ++cross_rows_of[I];
             }
-            cum += cnt;
         }
     }
     // Late items: whole items off the end of the local list, at most late_units chunk-units and at most half
