@@ -774,6 +774,7 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
         const uint32_t r0 = row_lo[g], r1 = row_hi[g];
+#pragma unroll 4      // four independent 16-byte loads in flight per thread; the adds keep their order
         for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
             real2 b0, b1;
             load_pair(slab_s + (size_t)r * SYM_SB + loc, b0, b1);        // rows are whole tiles: loc + 1 is inside
