@@ -18,6 +18,11 @@
  *                            communication stream per handle, event-ordered, no host sync in the loop); needs one device
  *                            per shard.  -shards 1 -rccl runs the sharded protocol with ONE rank (NB_FLAG_SHARD_SINGLE):
  *                            the whole split-step + RCCL path on a one-GPU box
+ *              [-rank R -world P -idfile F [-device D]]  ONE PROCESS PER GPU, plain C: this process is rank R of P; rank 0
+ *                            creates the RCCL id (nb_comm_unique_id) and publishes it through file F (written to F.tmp, then
+ *                            renamed), the others wait for F; every rank builds the same initial bodies, owns block R, and
+ *                            the whole step loop is nb_comm_step.  Launch: for r in 0..P-1: nbody_main -rank $r -world P -idfile F &
+ *                            (-world 1 runs the sharded protocol with one rank: the single-GPU rehearsal)
  * -load FILE restarts from a dump: eps, dt, precision, rsqrt mode, sum order, integrator and extras come from its
  * header unless the command line gives them (options are applied in order, so put -load first to override).
  */
@@ -27,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 static double now_s(void)
 {
@@ -43,6 +49,8 @@ int main(int argc, char **argv)
     size_t n = 65536;
     uint64_t frame0 = 0;
     int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0, rccl = 0, shards_given = 0;
+    int rank = -1, world = 0, device = -1;
+    const char *idfile = NULL;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
     nb_params p;
@@ -79,6 +87,10 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-shards") && i + 1 < argc) { shards = atoi(argv[++i]); shards_given = 1; }
         else if (!strcmp(argv[i], "-rccl")) rccl = 1;
+        else if (!strcmp(argv[i], "-rank") && i + 1 < argc) rank = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-world") && i + 1 < argc) world = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-idfile") && i + 1 < argc) idfile = argv[++i];
         else DIE("unknown argument %s", argv[i]);
     }
 
@@ -99,6 +111,63 @@ int main(int argc, char **argv)
         else CHECK(nb_plummer_2d(bodies, n, seed));
     }
 
+    if (world > 0) {
+        /* one process per GPU: this process is rank `rank` of `world`; the communicator is formed from an id file */
+        if (rank < 0 || rank >= world || !idfile || n % (size_t)world) DIE("-rank R -world P -idfile F: 0 <= R < P, P must divide n");
+        const int ndev = nb_device_count();
+        const size_t blk = n / (size_t)world;
+        nb_params q = p;
+        q.device = device >= 0 ? device : (ndev > 0 ? rank % ndev : 0);
+        q.shard_rank = rank; q.shard_world = world;
+        q.i_begin = (uint64_t)rank * blk; q.i_count = blk;
+        if (p.flags & NB_FLAG_SHARD_ALLREDUCE) { q.i_begin = 0; q.i_count = n; }
+        if (world == 1) q.flags |= NB_FLAG_SHARD_SINGLE;
+        nb_sim *h = nb_create(bodies, n, &q);
+        if (!h) DIE("nb_create(rank %d): %s", rank, nb_last_error());
+        char id[NB_COMM_ID_BYTES], tmpname[4096];
+        if (rank == 0) {
+            CHECK(nb_comm_unique_id(id));
+            snprintf(tmpname, sizeof tmpname, "%s.tmp", idfile);
+            FILE *f = fopen(tmpname, "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmpname, idfile) != 0) DIE("cannot publish the RCCL id in %s", idfile);
+        } else {
+            FILE *f = NULL;
+            const struct timespec tenth = {0, 100000000L};
+            for (int tries = 0; tries < 600 && !(f = fopen(idfile, "rb")); ++tries) nanosleep(&tenth, NULL);   /* up to 60 s for rank 0 */
+            if (!f || fread(id, 1, sizeof id, f) != sizeof id) DIE("rank %d: no RCCL id in %s after 60 s", rank, idfile);
+            fclose(f);
+        }
+        nb_comm *comm = nb_comm_create_rank(h, id, rank, world);
+        if (!comm) DIE("nb_comm_create_rank(rank %d of %d): %s", rank, world, nb_last_error());
+        int proto = 0, ver = 0;
+        CHECK(nb_comm_info(comm, &proto, NULL, NULL, &ver));
+        CHECK(nb_comm_step(comm, p.dt, 2));                /* warm-up: RCCL channels, first launches */
+        CHECK(nb_comm_wait(comm));
+        const double t0r = now_s();
+        CHECK(nb_comm_step(comm, p.dt, steps));
+        const double t_enq = now_s() - t0r;
+        CHECK(nb_comm_wait(comm));
+        const double pers = (now_s() - t0r) / steps;
+        double pm[3], lz;
+        CHECK(nb_momentum(h, pm, &lz));
+        CHECK(nb_sync(h, bodies + (proto == NB_SHARD_ALLREDUCE ? 0 : (size_t)rank * blk)));
+        printf("rank %d of %d on device %d: protocol=%s RCCL %d.%d.%d frame=%llu  %.3f ms/step (this rank's clock)  %.3e pair interactions/s  "
+               "host enqueue %.1f us/step  block momentum (%.6e, %.6e)\n", rank, world, q.device,
+               proto == NB_SHARD_SYMMETRIC ? "symmetric" : proto == NB_SHARD_ALLREDUCE ? "allreduce" : proto == NB_SHARD_ALLGATHER ? "allgather" : "none",
+               ver / 10000, ver / 100 % 100, ver % 100, (unsigned long long)nb_frame(h), pers * 1e3, (double)n * (double)n / pers, t_enq / steps * 1e6, pm[0], pm[1]);
+        if (dump) {                                        /* every rank dumps its own block (whole system for the replicated protocol) */
+            char name[4096];
+            snprintf(name, sizeof name, "%s.rank%d", dump, rank);
+            const size_t first = proto == NB_SHARD_ALLREDUCE ? 0 : (size_t)rank * blk, cnt = proto == NB_SHARD_ALLREDUCE ? n : blk;
+            CHECK(nb_write_bodies(name, bodies + first, cnt, nb_frame(h), &p));
+            printf("dumped %zu bodies to %s\n", cnt, name);
+        }
+        nb_comm_destroy(comm);
+        nb_destroy(h);
+        if (rank == 0) unlink(idfile);
+        CHECK(nb_host_free(bodies));
+        return 0;
+    }
     if (shards > 1 || (shards_given && rccl)) {
         /* one process, `shards` handles: each integrates a contiguous block */
         if (shards < 1 || shards > 64 || n % (size_t)shards) DIE("-shards must divide n (and be 1..64)");

@@ -139,3 +139,25 @@ def test_c_driver_rccl_single_rank_matches_plain_run(tmp_path):
     bb, fb, _ = nb.read_bodies(b)
     assert fa == fb == 6
     assert np.max(np.abs(ba["pos"] - bb["pos"])) <= 2e-6 * np.max(np.abs(bb["pos"]))
+
+
+def test_c_driver_one_process_per_gpu_form(tmp_path):
+    """`nbody_main -rank 0 -world 1 -idfile F`: the one-process-per-GPU launcher in plain C — RCCL id through a file,
+    ncclCommInitRank, nb_comm_step — with the one rank this box allows; same trajectory as the in-process run."""
+    exe = ROOT / "build" / "nbody_main"
+    idf, a, b = tmp_path / "rccl.id", tmp_path / "mp.nbd", tmp_path / "inproc.nbd"
+    common = ["-n", "65536", "-s", "4", "-eps", "0.05"]
+    r = subprocess.run([str(exe), *common, "-rank", "0", "-world", "1", "-idfile", str(idf), "-dump", str(a)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 of 1" in r.stdout and "protocol=symmetric" in r.stdout and not idf.exists()
+    r2 = subprocess.run([str(exe), *common, "-shards", "2", "-dump", str(b)], capture_output=True, text=True, timeout=240)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    ba, fa, _ = nb.read_bodies(str(a) + ".rank0")
+    bb, fb, _ = nb.read_bodies(b)
+    assert fa == 6 and fb == 4                       # the per-rank form runs 2 warm-up steps first
+    r3 = subprocess.run([str(exe), *common, "-s", "6", "-shards", "2", "-dump", str(b)], capture_output=True, text=True, timeout=240)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    bb, fb, _ = nb.read_bodies(b)
+    assert fb == 6 and np.max(np.abs(ba["pos"] - bb["pos"])) <= 2e-6 * np.max(np.abs(bb["pos"]))
+    bad = subprocess.run([str(exe), *common, "-rank", "1", "-world", "1", "-idfile", str(idf)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "0 <= R < P" in bad.stderr
