@@ -35,6 +35,12 @@ STATUS: the RCCL path with more than one rank has not run on hardware yet (no mu
 box is reachable from the build container); it is rehearsed over gloo and through RCCL
 with one rank (tests/test_dist_gpu.py, tests/test_dist_gloo.py).
 
+Two hosts can run the step loop (``driver=``): this module (torch.distributed issues the
+collectives between the library's split-step calls: 30-120 us of host time per step), or
+the library itself (``driver="c"``: ``nb_comm_step``, nbodysim_amd/csrc/nb_comm.cpp — RCCL
+collectives on a communication stream, event-ordered, one foreign call for any number of
+steps: 31-40 us per step); ``driver="tune"`` lets both compete in the start-up timing.
+
 The reference has no distributed code at all; this layer is new.
 PyTorch is plumbing here (device buffers, streams, the process group); the
 force/integrate work is the C ABI's.
