@@ -23,8 +23,11 @@ Extra objects in the line:
                 issues are fewer: `executed_tflops` / `executed_frac` count those
                 (17 flop per unordered pair) and are the honest "fraction of the
                 ALU peak" figure; `valu_busy` comes from the PMC profile of the round.
-                `traffic` = HBM bytes of one launch derived from the work plan
-                (slab rows written + positions read); `traffic_pmc` = the counter
+                `traffic` = HBM bytes of one launch of the dominant kernel: the PMC
+                measurement of this command kept under profiles/ (separate rocprofv3
+                --pmc passes, FETCH_SIZE x2 correction) when it exists for this
+                workload, else the figure derived from the work plan (`traffic_plan`:
+                slab rows written + positions read); `traffic_pmc` = the counter
                 measurement kept under profiles/ (cross-check).
   cpu_baseline  the oracle (C restatement of the reference's pairwise loop, the
                 reference's own arithmetic) timed on this box's host cores over
@@ -491,8 +494,13 @@ def main() -> None:
                 "valu_busy": pmc.get("valu_busy") if pmc_ok else None,
                 "valu_busy_source": ("profiles/hbm_traffic.json: a separate rocprofv3 --pmc run of this command on ANOTHER MI355X box, "
                                      "not a measurement of this run") if pmc_ok else None,
-                "traffic": traffic,
-                "traffic_source": "work plan: stationary slab rows + travelling partials written once per launch + positions read once",
+                "traffic": traffic_pmc if traffic_pmc else traffic,
+                "traffic_source": ("PMC: profiles/hbm_traffic.json (separate rocprofv3 --pmc passes of this command on an MI355X: FETCH_SIZE x2 "
+                                   "+ WRITE_SIZE per launch of the force kernel); the plan-derived figure is traffic_plan"
+                                   if traffic_pmc else
+                                   "work plan (no PMC file for this workload): stationary slab rows + travelling partials written once per "
+                                   "launch + positions read once"),
+                "traffic_plan": traffic,
                 "traffic_pmc": traffic_pmc,
                 "flop_per_pair": flop_per_pair,
                 "kernel": kernel,
