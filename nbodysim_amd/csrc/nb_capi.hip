@@ -287,9 +287,9 @@ static uint32_t late_units_for(const nb_params &p, bool fp64, int cus, uint32_t 
 // Rank-independent (n and parameters only): it shapes the plan every rank must agree on.
 static bool want_pairs(const nb_params &p, size_t n)
 {
-    if (p.precision == NB_FP64 || p.dims == 3) return false;
+    if (p.precision == NB_FP64) return false;
     if (p.sym_chunk_pairs) return p.sym_chunk_pairs > 0;
-    return n >= 65536;
+    return n >= 65536;                           // 2-D and 3-D (3-D with individual masses keeps the single-chunk kernel: launch_sym_items)
 }
 
 static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t world, bool sharded, size_t n)
@@ -820,13 +820,19 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         const float eps2 = s->p.eps * s->p.eps;
         const float4 *pos = (const float4 *)s->pos[s->cur];
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
+#define NB_SYM3_LAUNCH(RQ, UMB, PR, UMV) force_sym3_f32<RQ, UMB, PR><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, UMV)
+        // chunk pairs in 3-D pay with equal masses only (-1 ... -3 %); with individual masses the pair body needs 216 VGPRs
+        // (2 waves per SIMD) and loses 4 % (profiles/r03_chunk_pairs_3d.log): that case keeps the single-chunk sweep
+        // (any plan, even chunk counts included, runs on either kernel) unless nb_params.sym_chunk_pairs = 1 forces it
+        const bool pairs = s->sym_pairs && (s->uniform_mass || s->p.sym_chunk_pairs > 0);
         if (s->uniform_mass) {
-            if (quake) force_sym3_f32<RSQ_QUAKE, true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, s->um_mass);
-            else       force_sym3_f32<RSQ_EXACT, true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, s->um_mass);
+            if (quake) { if (pairs) NB_SYM3_LAUNCH(RSQ_QUAKE, true, true, s->um_mass); else NB_SYM3_LAUNCH(RSQ_QUAKE, true, false, s->um_mass); }
+            else       { if (pairs) NB_SYM3_LAUNCH(RSQ_EXACT, true, true, s->um_mass); else NB_SYM3_LAUNCH(RSQ_EXACT, true, false, s->um_mass); }
         } else {
-            if (quake) force_sym3_f32<RSQ_QUAKE, false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0f);
-            else       force_sym3_f32<RSQ_EXACT, false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0f);
+            if (quake) { if (pairs) NB_SYM3_LAUNCH(RSQ_QUAKE, false, true, 1.0f); else NB_SYM3_LAUNCH(RSQ_QUAKE, false, false, 1.0f); }
+            else       { if (pairs) NB_SYM3_LAUNCH(RSQ_EXACT, false, true, 1.0f); else NB_SYM3_LAUNCH(RSQ_EXACT, false, false, 1.0f); }
         }
+#undef NB_SYM3_LAUNCH
     } else if (s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
@@ -1725,7 +1731,8 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
-             (int)(s->sym || s->sym_sharded || s->sym_replicated), (int)(s->sym_pairs && !s->mass_scaled), s->sym_items, s->sym_L, s->sym_items_late,
+             (int)(s->sym || s->sym_sharded || s->sym_replicated),
+             (int)(s->sym_pairs && !s->mass_scaled && (!s->dims3 || s->uniform_mass || s->p.sym_chunk_pairs > 0)), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;
 }

@@ -261,12 +261,109 @@ void sym3_chunks(const float4 *__restrict__ pos, float4 *__restrict__ slab_r_row
     }
 }
 
-template <int RSQ, bool UM>
+// sym3_chunks2 — chunk PAIRS in 3-D (see sym_chunks2 in nb_kernels.hip.h): two travelling particles per lane in the two
+// halves of the packed registers, the stationary particle broadcast; 12 ds_bpermute_b32 per 16 pairs instead of 9 per 8.
+template <int RSQ, bool UM, bool DIAG>
+__device__ __forceinline__
+void sym3_chunks2(const float4 *__restrict__ pos, float4 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
+                  const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&zi)[SYM_P], const v2f (&mi)[SYM_P],
+                  v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], v2f (&az)[SYM_P], float eps2, float um_mass, float4 (*red)[4][64])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const int addr = (int)(((lane + 1u) & 63u) * 4u);
+    const v2f e2 = {eps2, eps2};
+    v2f bx[2 * SYM_P], by[2 * SYM_P], bz[2 * SYM_P];
+#pragma unroll
+    for (int k = 0; k < 2 * SYM_P; ++k) bx[k] = by[k] = bz[k] = (v2f){0.f, 0.f};
+    auto fetch = [&](uint32_t c, v2f &x, v2f &y, v2f &z, v2f &m) {
+        x = (v2f){PAD_XY, PAD_XY}; y = x; z = x; m = (v2f){0.f, 0.f};
+        if (c < cnt) {
+            const uint32_t j = (c0 + c) * SYM_CH + lane;
+            if (j < n) { const float4 pj = pos[j]; x.x = pj.x; y.x = pj.y; z.x = pj.z; m.x = pj.w; }
+        }
+        if (c + 1 < cnt) {
+            const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
+            if (j < n) { const float4 pj = pos[j]; x.y = pj.x; y.y = pj.y; z.y = pj.z; m.y = pj.w; }
+        }
+    };
+    v2f xq, yq, zq, mq;
+    fetch(0, xq, yq, zq, mq);
+    for (uint32_t c = 0; c < cnt; c += 2) {
+        v2f xn, yn, zn, mn;
+        fetch(c + 2, xn, yn, zn, mn);
+        v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f}, aqz = {0.f, 0.f};
+#pragma unroll 2
+        for (int step = 0; step < 64; ++step) {
+            const v2f xr = {lane_rot(xq.x, addr), lane_rot(xq.y, addr)};
+            const v2f yr = {lane_rot(yq.x, addr), lane_rot(yq.y, addr)};
+            const v2f zr = {lane_rot(zq.x, addr), lane_rot(zq.y, addr)};
+            v2f mr = {0.f, 0.f};
+            if constexpr (!UM) mr = (v2f){lane_rot(mq.x, addr), lane_rot(mq.y, addr)};
+#pragma unroll
+            for (int p = 0; p < SYM_P; ++p) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs = h ? xi[p].y : xi[p].x, ys = h ? yi[p].y : yi[p].x, zs = h ? zi[p].y : zi[p].x;
+                    const v2f dx = xq - (v2f){xs, xs}, dy = yq - (v2f){ys, ys}, dz = zq - (v2f){zs, zs};
+                    v2f r2 = __builtin_elementwise_fma(dx, dx, e2);
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    r2 = __builtin_elementwise_fma(dz, dz, r2);
+                    v2f inv;
+                    if constexpr (RSQ == RSQ_EXACT) inv = (v2f){__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                    else inv = quake_rsqrt2(r2);
+                    const v2f inv3 = inv * (inv * inv);
+                    v2f si = inv3, sj = inv3;
+                    if constexpr (!UM) { const float ms = h ? mi[p].y : mi[p].x; si = mq * inv3; sj = (v2f){ms, ms} * inv3; }
+                    bx[2 * p + h] = __builtin_elementwise_fma(si, dx, bx[2 * p + h]);
+                    by[2 * p + h] = __builtin_elementwise_fma(si, dy, by[2 * p + h]);
+                    bz[2 * p + h] = __builtin_elementwise_fma(si, dz, bz[2 * p + h]);
+                    if constexpr (!DIAG) {
+                        aqx = __builtin_elementwise_fma(-sj, dx, aqx);
+                        aqy = __builtin_elementwise_fma(-sj, dy, aqy);
+                        aqz = __builtin_elementwise_fma(-sj, dz, aqz);
+                    }
+                }
+            }
+            xq = xr; yq = yr; zq = zr;
+            if constexpr (!UM) mq = mr;
+            if constexpr (!DIAG) {
+                aqx = (v2f){lane_rot(aqx.x, addr), lane_rot(aqx.y, addr)};
+                aqy = (v2f){lane_rot(aqy.x, addr), lane_rot(aqy.y, addr)};
+                aqz = (v2f){lane_rot(aqz.x, addr), lane_rot(aqz.y, addr)};
+            }
+        }
+        if constexpr (!DIAG) {
+            float4 r0 = make_float4(aqx.x, aqy.x, aqz.x, 0.f), r1 = make_float4(aqx.y, aqy.y, aqz.y, 0.f);
+            if constexpr (UM) { r0.x *= um_mass; r0.y *= um_mass; r0.z *= um_mass; r1.x *= um_mass; r1.y *= um_mass; r1.z *= um_mass; }
+            float4 (*rb)[4][64] = red + 2u * ((c >> 1) & 1u);         // double buffered: [half q0 | half q1][4 waves][64 lanes]
+            rb[0][w][lane] = r0;
+            rb[1][w][lane] = r1;
+            __syncthreads();
+            if (w < 2 && c + w < cnt) {                                // wave 0 stores chunk c, wave 1 chunk c + 1
+                const uint32_t j = (c0 + c + w) * SYM_CH + lane;
+                float4 a = rb[w][0][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { a.x += rb[w][k][lane].x; a.y += rb[w][k][lane].y; a.z += rb[w][k][lane].z; }
+                if (j < n) slab_r_row[j] = a;
+            }
+        }
+        xq = xn; yq = yn; zq = zn;
+        if constexpr (!UM) mq = mn;
+    }
+#pragma unroll
+    for (int p = 0; p < SYM_P; ++p) {
+        ax[p] += (v2f){bx[2 * p].x + bx[2 * p].y, bx[2 * p + 1].x + bx[2 * p + 1].y};
+        ay[p] += (v2f){by[2 * p].x + by[2 * p].y, by[2 * p + 1].x + by[2 * p + 1].y};
+        az[p] += (v2f){bz[2 * p].x + bz[2 * p].y, bz[2 * p + 1].x + bz[2 * p + 1].y};
+    }
+}
+
+template <int RSQ, bool UM, bool PAIRS = false>
 __global__ __launch_bounds__(BLOCK)
 void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ items,
                     float4 *__restrict__ slab_s, float4 *__restrict__ slab_r, uint32_t n, float eps2, float um_mass)
 {
-    __shared__ float4 red[2][4][64];
+    __shared__ float4 red[PAIRS ? 4 : 2][4][64];
     const SymItem it = items[blockIdx.x];
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     v2f xi[SYM_P], yi[SYM_P], zi[SYM_P], mi[SYM_P], ax[SYM_P], ay[SYM_P], az[SYM_P];
@@ -282,8 +379,13 @@ void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ 
         ax[p] = ay[p] = az[p] = (v2f){0.f, 0.f};
     }
     float4 *__restrict__ rrow = slab_r + it.r_base;
-    if (it.diag) sym3_chunks<RSQ, UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
-    else         sym3_chunks<RSQ, UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    if constexpr (PAIRS) {
+        if (it.diag) sym3_chunks2<RSQ, UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+        else         sym3_chunks2<RSQ, UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    } else {
+        if (it.diag) sym3_chunks<RSQ, UM, true>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+        else         sym3_chunks<RSQ, UM, false>(pos, rrow, n, it.c0, it.cnt, xi, yi, zi, mi, ax, ay, az, eps2, um_mass, red);
+    }
     float4 *__restrict__ out = slab_s + (size_t)it.s_row * SYM_SB;
 #pragma unroll
     for (int p = 0; p < SYM_P; ++p) {

@@ -67,6 +67,18 @@ def test_3d_symmetric_equals_one_sided_and_momentum_is_conserved():
             res[tag] = sim.accelerations().astype(np.float64)
     scale = np.max(np.abs(res["one_sided"]))
     assert np.max(np.abs(res["sym"] - res["one_sided"])) < 2e-5 * scale
+    # the chunk-pair sweep in 3-D (sym3_chunks2), equal and individual masses, even and odd (3) chunks per item, both rsqrt modes
+    gen = ic.copy()
+    gen["mass"] = (np.random.default_rng(4).uniform(0.5, 1.5, 30000) / 30000).astype(np.float32)
+    for bodies in (ic, gen):
+        for rsqrt in ("exact", "quake"):
+            with nb.Simulation(bodies, eps=0.02, dims=3, rsqrt=rsqrt, sym_chunk_pairs=-1) as sim:
+                single = sim.accelerations().astype(np.float64)
+            for chunks in (0, 3):
+                with nb.Simulation(bodies, eps=0.02, dims=3, rsqrt=rsqrt, sym_chunk_pairs=1, sym_chunks_per_item=chunks) as sim:
+                    assert "chunk_pairs=1" in sim.describe()
+                    pair = sim.accelerations().astype(np.float64)
+                assert np.max(np.abs(pair - single)) < 2e-6 * np.max(np.abs(single)), (rsqrt, chunks)
     m = ic["mass"].astype(np.float64)[:, None]
     assert np.abs((m * res["sym"]).sum(0)).max() < 1e-6 * np.abs(m * res["sym"]).sum(0).max()
     # nb_momentum in 3-D (mass rides in pos.w on the device): fp32 and fp64 handles against the host sum, before and after steps
