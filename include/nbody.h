@@ -156,8 +156,9 @@ typedef struct nb_params {
     int32_t  lanes_p;             /* one-sided kernel: packed particle pairs per lane (1, 2, 4) */
     float    sym_tail[3];         /* guided-tail thresholds (fractions of a launch's work from which items are cut
                                      into L/2, L/4, L/8 chunks); all 0 = 0.85, 0.94, 0.98 */
-    int32_t  sym_chunk_pairs;     /* symmetric fp32 2-D kernel: sweep the travelling chunks in PAIRS (two particles per lane, items
-                                     cut into even chunk counts): 0 auto (from 65 536 bodies on), 1 always, -1 never */
+    int32_t  sym_chunk_pairs;     /* symmetric fp32 kernels: sweep the travelling chunks in PAIRS (two particles per lane, items
+                                     cut into even chunk counts): 0 auto (from 65 536 bodies on; in 3-D with equal masses only),
+                                     1 always, -1 never */
     uint64_t first_frame;         /* value nb_frame() starts from: 0 for a new run, the dump header's frame for a restart
                                      (the reference's Simulation::frame, Simulation.hpp:53, starts at 0: :60) */
 } nb_params;
