@@ -228,3 +228,38 @@ def test_cxx_adaptor_overlapped_step_delivers_the_same_frames_one_call_late():
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"blocking=([0-9.]+) ms/frame overlapped=([0-9.]+) ms/frame differing_bodies=(\d+)", r.stdout)
     assert m and int(m.group(3)) == 0, r.stdout
+
+
+def test_handles_and_communicators_release_their_device_memory():
+    """Create / use / destroy a few dozen handles (plain, mass-scaled, single-rank sharded + nb_comm, snapshot, momentum,
+    energy): the free device memory comes back (a leak of a slab, a sigma array, partial-sum buffers, streams or events
+    would show as a steady loss)."""
+    import torch
+    from nbodysim_amd.comm import Comm
+    n = 65536
+    ic = nb.plummer_2d(n, 1)
+    gen = ic.copy()
+    gen["mass"] = (np.random.default_rng(2).uniform(0.5, 1.5, n) / n).astype(np.float32)
+
+    def cycle():
+        with nb.Simulation(ic, eps=0.05) as s:
+            s.advance(2, 1e-3); s.energy(); s.momentum(); s.sync()
+            out = nb.bodies_array(n)
+            s.snapshot_begin(out); s.advance(1, 1e-3); s.snapshot_wait()
+        with nb.Simulation(gen, eps=0.05, mass_scaling=True) as s:
+            s.advance(2, 1e-3); s.sync()
+        with nb.Simulation(ic, eps=0.05, shard_rank=0, shard_world=1, shard_single=True) as s:
+            with Comm.all([s]) as c:
+                c.step(3, 1e-3); c.wait()
+        with nb.PinnedBodies(n) as pb, nb.Simulation(ic, eps=0.05, precision="fp64") as s:
+            s.advance(1, 1e-3)
+            L.check("nb_sync", nb.load().nb_sync(s._h, pb.array.ctypes.data))
+
+    cycle()                                               # first use: runtime pools, RCCL, code objects
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory lost over 8 cycles: {(free0 - free1) / 2**20:.1f} MiB"
