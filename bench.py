@@ -148,17 +148,27 @@ class DeviceSampler:
         return out
 
 
-def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler_period=0.02):
+def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler_period=0.02, adaptive=True):
     """The settled rate: at least `min_seconds` of back-to-back steps AFTER the driver's timed region (whose 20 steps
-    sit before the power controller has settled), with the device clock / power of exactly that stretch."""
+    sit before the power controller has settled), with the device clock / power of exactly that stretch.  Single GPU
+    (`adaptive`): if the first batch — sized from the timed region's rate — ends early, further batches sized from the
+    rate measured so far follow until the stretch is long enough; with several ranks the one batch is sized from the
+    MAX-reduced time, so that every rank enqueues the same number of steps."""
     steps = max(20, int(min_seconds * 1e3 / max(ms_per_step_hint, 1e-3)) + 1)
     smp = DeviceSampler(period_s=sampler_period)
     smp.start()
     t0 = time.perf_counter()
-    advance(steps, dt)
-    wait()
+    done = 0
+    for _ in range(6):
+        advance(steps, dt)
+        wait()
+        done += steps
+        el = time.perf_counter() - t0
+        if not adaptive or el >= min_seconds:
+            break
+        steps = max(20, int((min_seconds - el) * 1.1 * done / el) + 1)
     el = time.perf_counter() - t0
-    return {"steps": steps, "seconds": el, "ms_per_step": el / steps * 1e3, "device_state": smp.stop()}
+    return {"steps": done, "seconds": el, "ms_per_step": el / done * 1e3, "device_state": smp.stop()}
 
 
 def cpu_baseline(ic, n, target_s=10.0):
@@ -355,7 +365,8 @@ def main() -> None:
         if events:
             inner.profile(True)
         barrier()
-        sustained = sustained_rate(advance, wait, DT, elapsed / max(1, args.steps) * 1e3, sampler_period=0.02 if world == 1 else 0.1)
+        sustained = sustained_rate(advance, wait, DT, elapsed / max(1, args.steps) * 1e3, sampler_period=0.02 if world == 1 else 0.1,
+                                   adaptive=world == 1)
         barrier()
         if events:
             sms, sl = inner.profile_read()

@@ -54,7 +54,7 @@ def test_bench_line_contract():
     assert abs(d["energy"]["rel_drift"]) < 1e-3
     # burst vs settled: >= 2 s of steps AFTER the timed region, with their own clock / power samples; never part of `value`
     su = d["sustained"]
-    assert su["steps"] >= 20 and su["seconds"] >= 0.5 and su["ms_per_step"] > 0 and 0 < su["frac"] < 1.2
+    assert su["steps"] >= 20 and su["seconds"] >= 1.9 and su["ms_per_step"] > 0 and 0 < su["frac"] < 1.2
     assert abs(su["value"] - 32768.0 ** 2 * su["steps"] / su["seconds"]) < 1e-6 * su["value"]
     sc = rf["general_mass_scaled"]
     assert sc["mass_scaled"] is True and g["mass_scaled"] is False and sc["avg_launch_ms"] > 0
