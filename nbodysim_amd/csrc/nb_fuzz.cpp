@@ -113,10 +113,13 @@ static void fuzz_planner(int cases, std::mt19937 &rng)
         if (world > 1 && rng() % 2) t.late_units = rng() % 3000;
         t.late_chunks = 1 + rng() % 3;
         t.guided_tail = rng() % 4 != 0;
+        t.even_chunks = rng() % 2 != 0;           // handles that sweep chunk pairs
+        if (rng() % 5 == 0) t.wg_per_cu = 8 + rng() % 32;
         if (rng() % 4 == 0) { t.tail_at[0] = 0.3; t.tail_at[1] = 0.6; t.tail_at[2] = 0.9; }
         check_plan_case(n, world, cus, t);
     }
     check_plan_case(262144, 8, 256, SymTuning{});                                 // the benchmark's split
+    { SymTuning e; e.even_chunks = true; e.late_units = 1400; check_plan_case(262144, 8, 256, e); check_plan_case(262144, 1, 256, e); check_plan_case(70001, 1, 256, e); }
     check_plan_case(1, 1, 256, SymTuning{});
     check_plan_case(2048, 1, 256, SymTuning{});
     check_plan_case(2049, 1, 1, SymTuning{});
