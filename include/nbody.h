@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 3
+#define NB_ABI_VERSION 4
 
 /* ---- particle record -------------------------------------------------------
  * Bit-compatible with the reference's `struct alignas(16) Body`
@@ -161,6 +161,11 @@ typedef struct nb_params {
                                      1 always, -1 never */
     uint64_t first_frame;         /* value nb_frame() starts from: 0 for a new run, the dump header's frame for a restart
                                      (the reference's Simulation::frame, Simulation.hpp:53, starts at 0: :60) */
+    int32_t  sym_tile;            /* symmetric fp32 2-D kernels, single handle: stationary particles per work-item tile.  2048 = the
+                                     classic form (4 waves x 512 different particles); 512 = the wave-split form (the 4 waves share 512
+                                     particles and split the item's chunks: finer work units and 4-KiB slab rows for small and
+                                     mid-size systems, 4x the travelling partials per pair); 0 = automatic (512 below 49 152 bodies) */
+    int32_t  _reserved0;          /* keeps sizeof(nb_params) a multiple of 8 whatever the compiler; must be 0 */
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
@@ -401,7 +406,7 @@ int nb_plummer_3d(nb_body *out, size_t n, uint32_t seed);
 int nb_default_ics(nb_body *out, size_t n);
 
 /* ---- the symmetric kernel's work plan ------------------------------------------ */
-/* One work item (= one workgroup of force_sym_*): tile `tile` (2048 particles) against the 64-particle
+/* One work item (= one workgroup of force_sym_*): tile `tile` (nb_sym_info.tile_particles particles) against the 64-particle
  * chunks [c0, c0 + cnt).  s_row: row of the stationary slab it writes; the travelling partial of particle
  * j goes to element r_base + j of the travelling slab (diag items write none); group: 0 = local (pairs
  * inside the rank's own block), 1 = cross-block, 2 = late (held-back local). */
@@ -423,6 +428,8 @@ typedef struct nb_sym_info {
     uint64_t cross_units_total; /* cross-block units of ALL ranks: equal on every rank of a run */
     uint64_t slab_s_bytes, slab_r_bytes;             /* the two partial-sum slab sets (written once, read once per step) */
     uint64_t coverage_entries;
+    uint32_t tile_particles;    /* stationary particles per tile of this plan: 2048 (classic) or 512 (wave-split kernels) */
+    uint32_t _reserved0;
 } nb_sym_info;
 int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out);
 

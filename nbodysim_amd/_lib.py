@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libnbody_hip.so"
 
-NB_ABI_VERSION = 3
+NB_ABI_VERSION = 4
 
 # enums (include/nbody.h)
 NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -88,6 +88,8 @@ class nb_params(C.Structure):
         ("sym_tail", C.c_float * 3),
         ("sym_chunk_pairs", C.c_int32),
         ("first_frame", C.c_uint64),
+        ("sym_tile", C.c_int32),
+        ("_reserved0", C.c_int32),
     ]
 
 
@@ -113,10 +115,12 @@ class nb_sym_info(C.Structure):
         ("slab_s_bytes", C.c_uint64),
         ("slab_r_bytes", C.c_uint64),
         ("coverage_entries", C.c_uint64),
+        ("tile_particles", C.c_uint32),
+        ("_reserved0", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size"}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size" and not k.startswith("_")}
 
 
 #: numpy view of ``nb_sym_item`` (32 bytes)

@@ -101,6 +101,7 @@ struct nb_sim {
     bool sym = false;
     uint32_t sym_items = 0, sym_items_local = 0, sym_items_cross = 0, sym_items_late = 0;   // [local | cross | late]
     uint32_t sym_tiles = 0, sym_rows = 0, sym_L = 0, sym_cov_late_off = 0;
+    uint32_t sym_sb = SYM_SB, sym_sb_shift = 11;   // particles per block-tile of the plan: 2048 (classic) or 512 (wave-split kernels)
     SymItem *sym_items_dev = nullptr;          // local items first, then the cross-block items
     uint32_t *sym_rowbase_dev = nullptr;       // 3 x tiles: first row / first late row / end row of every tile
     uint32_t *sym_cov_begin_dev = nullptr;     // 2 x (tiles + 1): coverage-list bounds of the main and the late gather
@@ -215,6 +216,22 @@ static void plan(nb_sim *s)
 // Below that (and for eps = 0) the one-sided kernels keep the reference's `if (r_sq > 0)` guard (Quadtree.hpp:139).
 static bool needs_guard(const nb_sim *s) { return s->fp64 ? !(s->p.eps > 0.0f) : !(s->p.eps >= 1e-12f); }
 
+// Block-tile of a handle's symmetric plan.  The WAVE-SPLIT kernels (force_sym_f32<..., WS>: tiles of 512, the 4 waves of a
+// workgroup share the stationary particles and split the chunks) give the planner work units a quarter the size, items
+// whose stationary row is 4 KiB instead of 16, and a sweep without barriers — what small and mid-size systems need to
+// fill 1024 resident workgroup slots evenly — for four times the travelling partials per pair, which large systems do not
+// pay back.  Measured (tools/ws_sweep.py, profiles/r04_ws_sweep.log): -3 ... -4 % step time at N = 25 000 (reference
+// workload), -2.5 % at 16 384 and 32 768, neutral at 65 536, +1.3 ... +2.6 % at 131 072: used below 49 152 bodies.
+// fp32 2-D, single handle (a rank of a sharded run keeps the classic tiles: its blocks are whole 2048-particle tiles).
+// nb_params.sym_tile = 512 / 2048 forces one.  Rank-independent (n and parameters only).
+constexpr size_t SYM_WS_MAX_N = 49152;
+static uint32_t sym_tile_of(const nb_params &p, size_t n)
+{
+    if (p.precision == NB_FP64 || p.dims == 3 || p.shard_world > 1 || (p.flags & NB_FLAG_SHARD_SINGLE)) return SYM_SB;
+    if (p.sym_tile) return (uint32_t)p.sym_tile;
+    return n < SYM_WS_MAX_N ? SYM_SB_WS : SYM_SB;
+}
+
 static bool sym_eligible(const nb_sim *s)
 {
     if (s->p.flags & NB_FLAG_NO_SYMMETRY) return false;
@@ -235,7 +252,7 @@ static bool sym_eligible(const nb_sim *s)
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)24 << 30; }
         if (free_b / 3 < cap) cap = free_b / 3;
     }
-    if (sym_slab_r_bound((uint32_t)s->n, world) * s->esz > cap) return false;
+    if (sym_slab_r_bound((uint32_t)s->n, world, sym_tile_of(s->p, s->n)) * s->esz > cap) return false;
     return true;
 }
 
@@ -300,6 +317,7 @@ static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t worl
     t.wg_per_cu = sharded ? 24u : 0u;             // reduce-scatter protocol: two launches per step (nb_plan.cpp)
     t.late_chunks = fp64 ? 1u : 2u;
     t.even_chunks = want_pairs(p, n);            // the kernel sweeps chunk pairs: even chunk counts
+    t.sb = sym_tile_of(p, n);
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
         for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k];
@@ -320,8 +338,9 @@ static void fill_sym_info(const SymPlan &pl, uint32_t n, uint32_t world, int cus
     out->segments = (uint32_t)pl.segs.size();
     out->cus = (uint32_t)cus;
     out->units_local = pl.units_local; out->units_cross = pl.units_cross; out->units_late = pl.units_late;
-    sym_units(n, world, nullptr, &out->cross_units_total);
-    out->slab_s_bytes = (uint64_t)out->rows_s * SYM_SB * esz;
+    sym_units(n, world, nullptr, &out->cross_units_total, pl.sb);
+    out->slab_s_bytes = (uint64_t)out->rows_s * pl.sb * esz;
+    out->tile_particles = pl.sb;
     out->slab_r_bytes = pl.slab_r_elems * esz;
     out->coverage_entries = pl.cov_main.size() + pl.cov_late.size();
 }
@@ -338,6 +357,7 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
     if (info && info->struct_size != sizeof(nb_sym_info)) return nb_fail(NB_EINVAL, "nb_debug_sym_plan: info->struct_size");
     nb_params p;
     if (tuning) p = *tuning; else nb_params_default(&p);
+    p.shard_rank = rank; p.shard_world = world;        // what a handle of this (rank, world) would carry: selects the tile size too
     const bool fp64 = p.precision == NB_FP64;
     SymPlan pl;
     build_sym_plan((uint32_t)n, (uint32_t)cus, (uint32_t)rank, (uint32_t)world, tuning_of(p, fp64, cus, (uint32_t)world, world > 1, n), pl);
@@ -479,6 +499,7 @@ static int plan_sym(nb_sim *s)
     fill_sym_info(pl, n, world, s->cus, s->esz, true, &s->sym_info);
     s->sym_items_local = pl.n_local; s->sym_items_cross = pl.n_cross; s->sym_items_late = pl.n_late;
     s->sym_items = (uint32_t)pl.items.size(); s->sym_tiles = tiles; s->sym_rows = row; s->sym_L = pl.L;
+    s->sym_sb = pl.sb; s->sym_sb_shift = pl.sb == SYM_SB_WS ? 9u : 11u;
     // row bounds for the gathers: [lo | mid | hi] = rowbase[0..tiles), rowmid[0..tiles), rowbase[1..tiles]
     std::vector<uint32_t> bounds(3 * (size_t)tiles);
     for (uint32_t g = 0; g < tiles; ++g) { bounds[g] = pl.rowbase[g]; bounds[tiles + g] = pl.rowmid[g]; bounds[2 * (size_t)tiles + g] = pl.rowbase[g + 1]; }
@@ -492,7 +513,7 @@ static int plan_sym(nb_sim *s)
     HIPCHK(hipMalloc((void **)&s->sym_rowbase_dev, bounds.size() * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&s->sym_cov_begin_dev, cbegin.size() * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&s->sym_cov_dev, (cov.size() ? cov.size() : 1) * sizeof(SymCov)));
-    HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * SYM_SB * s->esz));
+    HIPCHK(hipMalloc(&s->sym_slab_s, (size_t)(row ? row : 1) * pl.sb * s->esz));
     HIPCHK(hipMalloc(&s->sym_slab_r, (size_t)(pl.slab_r_elems ? pl.slab_r_elems : 1) * s->esz));
     int rc;
     if ((rc = copy_h2d(s, s->sym_items_dev, pl.items.data(), pl.items.size() * sizeof(SymItem)))) return rc;
@@ -630,8 +651,9 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
+        (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
         (p.lanes_p != 0 && p.lanes_p != 1 && p.lanes_p != 2 && p.lanes_p != 4) || !(p.sym_late_us == p.sym_late_us)) {
-        nb_set_error("nb_create: tuning field out of range (sym_chunks_per_item >= 0, sym_aux_stream in -1..1, lanes_p in {0,1,2,4}, j_slices >= 0)");
+        nb_set_error("nb_create: tuning field out of range (sym_chunks_per_item >= 0, sym_aux_stream in -1..1, lanes_p in {0,1,2,4}, j_slices >= 0, sym_tile in {0,512,2048})");
         return nullptr;
     }
     if (p.sym_tail[0] != 0.0f || p.sym_tail[1] != 0.0f || p.sym_tail[2] != 0.0f) {
@@ -640,6 +662,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
             return nullptr;
         }
     }
+    if (p._reserved0 != 0) { nb_set_error("nb_create: params->_reserved0 must be 0 (use nb_params_default)"); return nullptr; }
     if (p.dims == 0) p.dims = 2;
     if (p.dims != 2 && p.dims != 3) { nb_set_error("nb_create: dims must be 2 or 3"); return nullptr; }
     if (p.dims == 3 && (p.sum_order != NB_SUM_TILED || p.extras != 0)) {
@@ -845,7 +868,11 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         const float *mass = (const float *)s->mass;
         float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
         const float *sg = s->sigma;
-#define NB_SYM_LAUNCH(RQ, MMODE, PR, UMV) force_sym_f32<RQ, MMODE, PR><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV)
+#define NB_SYM_LAUNCH(RQ, MMODE, PR, UMV)                                                                                         \
+        do {                                                                                                                      \
+            if (s->sym_sb == SYM_SB_WS) force_sym_f32<RQ, MMODE, PR, true><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV);  \
+            else                        force_sym_f32<RQ, MMODE, PR, false><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV); \
+        } while (0)
         const bool pairs = s->sym_pairs && !s->mass_scaled;          // chunk pairs (sym_chunks2): large systems, see want_pairs
         if (s->uniform_mass) {
             if (quake) { if (pairs) NB_SYM_LAUNCH(RSQ_QUAKE, MM_UNIFORM, true, s->um_mass); else NB_SYM_LAUNCH(RSQ_QUAKE, MM_UNIFORM, false, s->um_mass); }
@@ -896,19 +923,19 @@ static int launch_sym_gather(nb_sim *s, bool fuse_step, double dt)
         if (fuse_step)
             sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double2 *)dst, nullptr,
                                                                   (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
-                                                                  dt, dt, s->p.extras, kd);
+                                                                  dt, dt, s->p.extras, kd, s->sym_sb_shift);
         else
             sym_gather<double, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (double2 *)dst, nullptr,
-                                                                   nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0);
+                                                                   nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, 0, s->sym_sb_shift);
     } else {
         const float2 *ss = (const float2 *)s->sym_slab_s, *sr = (const float2 *)s->sym_slab_r;
         if (fuse_step)
             sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float2 *)dst, nullptr,
                                                                  (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
-                                                                 (float)dt, (float)dt, s->p.extras, kd);
+                                                                 (float)dt, (float)dt, s->p.extras, kd, s->sym_sb_shift);
         else
             sym_gather<float, false><<<gg, BLOCK, 0, s->stream>>>(ss, sr, lo, hi, cb, s->sym_cov_dev, n, 0u, n, (float2 *)dst, nullptr,
-                                                                  nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0);
+                                                                  nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, s->sym_sb_shift);
     }
     HIPCHK(hipGetLastError());
     return NB_OK;
@@ -938,12 +965,12 @@ static int launch_sym_gather_late(nb_sim *s, double dt)
         sym_gather<double, true><<<gg, BLOCK, 0, s->stream>>>((const double2 *)s->sym_slab_s, (const double2 *)s->sym_slab_r, lo, hi, cb, cov,
                                                               n, ib, ic, nullptr, (const double2 *)s->acc_owned,
                                                               (const double2 *)s->pos[s->cur], (double2 *)s->pos[nxt], (double2 *)s->vel, (double2 *)s->acc,
-                                                              dt, dt, s->p.extras, kd);
+                                                              dt, dt, s->p.extras, kd, s->sym_sb_shift);
     else
         sym_gather<float, true><<<gg, BLOCK, 0, s->stream>>>((const float2 *)s->sym_slab_s, (const float2 *)s->sym_slab_r, lo, hi, cb, cov,
                                                              n, ib, ic, nullptr, (const float2 *)s->acc_owned,
                                                              (const float2 *)s->pos[s->cur], (float2 *)s->pos[nxt], (float2 *)s->vel, (float2 *)s->acc,
-                                                             (float)dt, (float)dt, s->p.extras, kd);
+                                                             (float)dt, (float)dt, s->p.extras, kd, s->sym_sb_shift);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
@@ -1725,13 +1752,13 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
-             (int)(s->sym || s->sym_sharded || s->sym_replicated),
+             (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_sb,
              (int)(s->sym_pairs && !s->mass_scaled && (!s->dims3 || s->uniform_mass || s->p.sym_chunk_pairs > 0)), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;

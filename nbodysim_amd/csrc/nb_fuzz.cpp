@@ -37,16 +37,18 @@ using namespace nbk;
 
 static void check_plan_case(uint32_t n, uint32_t world, uint32_t cus, const SymTuning &tune)
 {
-    const uint32_t tiles = (n + SYM_SB - 1) / SYM_SB, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = SYM_SB / SYM_CH;
+    const uint32_t sb = tune.sb;
+    const uint32_t tiles = (n + sb - 1) / sb, chunks = (n + SYM_CH - 1) / SYM_CH, cpt = sb / SYM_CH;
     std::vector<uint8_t> cover((size_t)tiles * chunks, 0);
     uint64_t cross_seen = 0, cross_total = 0;
-    sym_units(n, world, nullptr, &cross_total);
+    sym_units(n, world, nullptr, &cross_total, sb);
     for (uint32_t rank = 0; rank < world; ++rank) {
         SymPlan pl;
         build_sym_plan(n, cus, rank, world, tune, pl);
-        REQUIRE(pl.tiles == tiles && pl.items.size() == (size_t)pl.n_local + pl.n_cross + pl.n_late, "n=%u world=%u", n, world);
-        REQUIRE(pl.slab_r_elems <= sym_slab_r_bound(n, world), "bound n=%u world=%u: %llu > %llu", n, world,
-                (unsigned long long)pl.slab_r_elems, (unsigned long long)sym_slab_r_bound(n, world));
+        REQUIRE(pl.tiles == tiles && pl.sb == sb && pl.items.size() == (size_t)pl.n_local + pl.n_cross + pl.n_late, "n=%u world=%u", n, world);
+        REQUIRE(pl.slab_r_elems <= sym_slab_r_bound(n, world, sb), "bound n=%u world=%u: %llu > %llu", n, world,
+                (unsigned long long)pl.slab_r_elems, (unsigned long long)sym_slab_r_bound(n, world, sb));
+        if (!tune.forced_L) REQUIRE(pl.L % tune.quantum() == 0, "L = %u is not a multiple of the kernel's chunk quantum %u", pl.L, tune.quantum());
         std::vector<uint8_t> row_used(pl.rowbase[tiles], 0);
         std::vector<std::pair<int64_t, int64_t>> ranges;
         for (const SymItem &it : pl.items) {
@@ -83,7 +85,7 @@ static void check_plan_case(uint32_t n, uint32_t world, uint32_t cus, const SymT
             for (size_t s = s0; s < s1; ++s) want += pl.segs[s].hi - pl.segs[s].lo;
             for (uint32_t t = 0; t < tiles; ++t)
                 for (uint32_t i = begin[t]; i < begin[t + 1]; ++i) {
-                    const uint32_t a = std::max(cov[i].lo, t * SYM_SB), b = std::min<uint64_t>(cov[i].hi, (uint64_t)(t + 1) * SYM_SB);
+                    const uint32_t a = std::max(cov[i].lo, t * sb), b = std::min<uint64_t>(cov[i].hi, (uint64_t)(t + 1) * sb);
                     REQUIRE(a < b, "coverage entry does not meet its tile");
                     REQUIRE(cov[i].base + (int64_t)a >= 0 && cov[i].base + (int64_t)b <= (int64_t)pl.slab_r_elems, "coverage outside the slab");
                     got += b - a;
@@ -114,12 +116,15 @@ static void fuzz_planner(int cases, std::mt19937 &rng)
         t.late_chunks = 1 + rng() % 3;
         t.guided_tail = rng() % 4 != 0;
         t.even_chunks = rng() % 2 != 0;           // handles that sweep chunk pairs
+        if (rng() % 2) t.sb = SYM_SB_WS;          // wave-split tiles (the product uses them for single handles; the planner takes any world)
         if (rng() % 5 == 0) t.wg_per_cu = 8 + rng() % 32;
         if (rng() % 4 == 0) { t.tail_at[0] = 0.3; t.tail_at[1] = 0.6; t.tail_at[2] = 0.9; }
         check_plan_case(n, world, cus, t);
     }
     check_plan_case(262144, 8, 256, SymTuning{});                                 // the benchmark's split
     { SymTuning e; e.even_chunks = true; e.late_units = 1400; check_plan_case(262144, 8, 256, e); check_plan_case(262144, 1, 256, e); check_plan_case(70001, 1, 256, e); }
+    { SymTuning w; w.sb = SYM_SB_WS; check_plan_case(25000, 1, 256, w); check_plan_case(65536, 1, 256, w); check_plan_case(1, 1, 256, w); check_plan_case(513, 1, 2, w);
+      w.even_chunks = true; check_plan_case(65536, 1, 256, w); check_plan_case(70001, 1, 256, w); check_plan_case(262144, 8, 256, w); }
     check_plan_case(1, 1, 256, SymTuning{});
     check_plan_case(2048, 1, 256, SymTuning{});
     check_plan_case(2049, 1, 1, SymTuning{});

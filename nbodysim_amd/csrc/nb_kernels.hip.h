@@ -440,7 +440,10 @@ __device__ __forceinline__ float lane_rot(float v, int addr)
 //               inside the float range — checked at upload (nb_capi.hip: mass_scaling_ok), otherwise MM_GENERAL runs.
 enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
 
-template <int RSQ, int MM, bool DIAG>
+// WS (wave split, force_sym_f32<..., WS = true>): the 4 waves of the workgroup hold the SAME stationary particles and
+// take the item's chunks in turn (wave w: chunks w, w + 4, ...), so a travelling partial is complete inside ONE wave
+// and is stored straight from the registers: no LDS combine, no barrier per chunk.
+template <int RSQ, int MM, bool DIAG, bool WS = false>
 __device__ __forceinline__
 void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -463,11 +466,13 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
             else { x = pj.x; y = pj.y; if constexpr (!UM) m = mass[j]; }
         }
     };
-    fetch(c0 * SYM_CH + lane, xq, yq, mq, eq);
-    for (uint32_t c = 0; c < cnt; ++c) {
+    constexpr uint32_t CS = WS ? 4u : 1u;              // chunk stride of this wave
+    const uint32_t cfirst = WS ? w : 0u;
+    fetch(cfirst < cnt ? (c0 + cfirst) * SYM_CH + lane : n, xq, yq, mq, eq);
+    for (uint32_t c = cfirst; c < cnt; c += CS) {
         // next chunk in flight behind the 64 steps
         float xn, yn, mn, en;
-        fetch(c + 1 < cnt ? (c0 + c + 1) * SYM_CH + lane : n, xn, yn, mn, en);
+        fetch(c + CS < cnt ? (c0 + c + CS) * SYM_CH + lane : n, xn, yn, mn, en);
         v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};
 #pragma unroll SYM_UNROLL
         for (int step = 0; step < 64; ++step) {
@@ -533,15 +538,20 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
             float2 r = make_float2(aqx.x + aqx.y, aqy.x + aqy.y);
             if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; }
             if constexpr (MS) { const float s2 = mq * mq; r.x *= s2; r.y *= s2; }      // / m_j: the particle is back in its home lane
-            float2 (*rb)[64] = red[c & 1u];
-            rb[w][lane] = r;
-            __syncthreads();
-            if (w == 0) {
-                const uint32_t j = (c0 + c) * SYM_CH + lane;
-                float2 a = rb[0][lane];
+            if constexpr (WS) {
+                const uint32_t j = (c0 + c) * SYM_CH + lane;      // this wave alone met the chunk: its sum is the partial
+                if (j < n) slab_r_row[j] = r;
+            } else {
+                float2 (*rb)[64] = red[c & 1u];
+                rb[w][lane] = r;
+                __syncthreads();
+                if (w == 0) {
+                    const uint32_t j = (c0 + c) * SYM_CH + lane;
+                    float2 a = rb[0][lane];
 #pragma unroll
-                for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; }
-                if (j < n) slab_r_row[j] = a;
+                    for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; }
+                    if (j < n) slab_r_row[j] = a;
+                }
             }
         }
         xq = xn; yq = yn;
@@ -561,7 +571,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
 // The stationary accumulators become per-particle pairs {from q0, from q1} (32 registers instead of 16), summed at the
 // end.  An odd chunk count leaves the second half of the last pair empty (PAD particles: half of that pair's work is
 // wasted), so the planner cuts items into even chunk counts for handles that run this kernel (SymTuning::even_chunks).
-template <int RSQ, int MM, bool DIAG>
+template <int RSQ, int MM, bool DIAG, bool WS = false>
 __device__ __forceinline__
 void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
                  float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -588,11 +598,12 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
             if (j < n) { const float2 pj = pos[j]; x.y = pj.x; y.y = pj.y; if constexpr (!UM) m.y = mass[j]; }
         }
     };
+    constexpr uint32_t CS = WS ? 8u : 2u;              // WS: wave w sweeps the chunk pairs 2w, 2w + 8, ...
     v2f xq, yq, mq;
-    fetch(0, xq, yq, mq);
-    for (uint32_t c = 0; c < cnt; c += 2) {
+    fetch(WS ? 2u * w : 0u, xq, yq, mq);
+    for (uint32_t c = WS ? 2u * w : 0u; c < cnt; c += CS) {
         v2f xn, yn, mn;
-        fetch(c + 2, xn, yn, mn);                      // next pair in flight behind the 64 steps
+        fetch(c + CS, xn, yn, mn);                     // next pair in flight behind the 64 steps
         v2f aqx = {0.f, 0.f}, aqy = {0.f, 0.f};         // {q0, q1}
 #pragma unroll SYM_UNROLL2
         for (int step = 0; step < 64; ++step) {
@@ -645,18 +656,24 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
             // in wave order; wave 0 stores chunk c, wave 1 chunk c + 1
             float4 r = make_float4(aqx.x, aqy.x, aqx.y, aqy.y);
             if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; r.z *= um_mass; r.w *= um_mass; }
-            float4 (*rb)[64] = red[(c >> 1) & 1u];
-            rb[w][lane] = r;
-            __syncthreads();
-            if (w < 2 && c + w < cnt) {
-                const uint32_t j = (c0 + c + w) * SYM_CH + lane;
-                float2 a = w ? make_float2(rb[0][lane].z, rb[0][lane].w) : make_float2(rb[0][lane].x, rb[0][lane].y);
+            if constexpr (WS) {
+                const uint32_t j0 = (c0 + c) * SYM_CH + lane, j1 = j0 + SYM_CH;
+                if (j0 < n) slab_r_row[j0] = make_float2(r.x, r.y);
+                if (c + 1 < cnt && j1 < n) slab_r_row[j1] = make_float2(r.z, r.w);
+            } else {
+                float4 (*rb)[64] = red[(c >> 1) & 1u];
+                rb[w][lane] = r;
+                __syncthreads();
+                if (w < 2 && c + w < cnt) {
+                    const uint32_t j = (c0 + c + w) * SYM_CH + lane;
+                    float2 a = w ? make_float2(rb[0][lane].z, rb[0][lane].w) : make_float2(rb[0][lane].x, rb[0][lane].y);
 #pragma unroll
-                for (int k = 1; k < 4; ++k) {
-                    a.x += w ? rb[k][lane].z : rb[k][lane].x;
-                    a.y += w ? rb[k][lane].w : rb[k][lane].y;
+                    for (int k = 1; k < 4; ++k) {
+                        a.x += w ? rb[k][lane].z : rb[k][lane].x;
+                        a.y += w ? rb[k][lane].w : rb[k][lane].y;
+                    }
+                    if (j < n) slab_r_row[j] = a;
                 }
-                if (j < n) slab_r_row[j] = a;
             }
         }
         xq = xn; yq = yn;
@@ -669,17 +686,26 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
     }
 }
 
-template <int RSQ, int MM, bool PAIRS = false>
-__global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
-void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
-                   const SymItem *__restrict__ items,
-                   float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
-                   uint32_t n, float eps2, float um_mass)
+// WS = true is the WAVE-SPLIT form for small and mid-size systems (tiles of SYM_SB_WS = 512 particles): all 4 waves
+// keep the SAME 512 stationary particles and share out the item's chunks (sym_chunks<..., WS>), so the unit of work a
+// planner can place is one wave x one chunk — a quarter of the classic tile's — the travelling partials need no
+// cross-wave combine (no barrier inside the sweep), and an item's stationary row is 4 KiB instead of 16.  The four
+// waves' stationary sums are added once, at the end, through LDS in wave order.  Price: four times the travelling
+// partials per pair (one per 512 x 64 instead of 2048 x 64 pairs), which is why large systems keep the classic form.
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
+__device__ __forceinline__
+void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
+                        const SymItem *__restrict__ items,
+                        float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
+                        uint32_t n, float eps2, float um_mass)
 {
     constexpr bool UM = MM == MM_UNIFORM;
+    constexpr uint32_t SB = WS ? SYM_SB_WS : SYM_SB;
     static_assert(!(PAIRS && MM == MM_SCALED), "the mass-scaled body keeps the one-chunk form");
-    __shared__ float4 red4[2][4][64];
+    static_assert(SYM_WT == SYM_SB_WS && (!WS || SYM_P == 4), "a wave-split tile is one wave's stationary set; wave w finishes register pair w");
+    __shared__ float4 red4[WS ? 4 * SYM_P : 2 * 4][64];          // classic: [2][4][64] chunk combine; WS: [4 waves][SYM_P][64] final sums
     float2 (*red)[4][64] = reinterpret_cast<float2 (*)[4][64]>(red4);
+    float4 (*red2)[4][64] = reinterpret_cast<float4 (*)[4][64]>(red4);
     const SymItem it = items[blockIdx.x];
     const bool diag = it.diag != 0;
     const uint32_t s_row = it.s_row;
@@ -689,8 +715,8 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
     uint32_t li[SYM_P];
 #pragma unroll
     for (int p = 0; p < SYM_P; ++p) {
-        li[p] = w * SYM_WT + (uint32_t)p * 128u + 2u * lane;      // index inside the block-tile
-        const uint32_t g0 = it.tile * SYM_SB + li[p], g1 = g0 + 1;
+        li[p] = (WS ? 0u : w * SYM_WT) + (uint32_t)p * 128u + 2u * lane;      // index inside the block-tile
+        const uint32_t g0 = it.tile * SB + li[p], g1 = g0 + 1;
         // particles past the end sit at PAD_XY with mass 0: they neither feel nor exert force
         float2 p0 = make_float2(PAD_XY, PAD_XY), p1 = p0;
         float m0 = 0.f, m1 = 0.f;
@@ -701,19 +727,42 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
     }
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
     if constexpr (PAIRS) {
-        if (diag) sym_chunks2<RSQ, MM, true>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red4);
-        else      sym_chunks2<RSQ, MM, false>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red4);
+        if (diag) sym_chunks2<RSQ, MM, true, WS>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
+        else      sym_chunks2<RSQ, MM, false, WS>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
     } else {
-        if (diag) sym_chunks<RSQ, MM, true>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
-        else      sym_chunks<RSQ, MM, false>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        if (diag) sym_chunks<RSQ, MM, true, WS>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        else      sym_chunks<RSQ, MM, false, WS>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     }
 
-    float2 *__restrict__ out = slab_s + (size_t)s_row * SYM_SB;
+    float2 *__restrict__ out = slab_s + (size_t)s_row * SB;
+    if constexpr (WS) {
+        // the 4 waves hold partial sums of the SAME 512 particles (each over its own chunks): add them in wave order;
+        // wave w finishes register pair p = w of every lane and stores its 128 particles (1 KiB)
 #pragma unroll
-    for (int p = 0; p < SYM_P; ++p) {
-        if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
-        *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+        for (int p = 0; p < SYM_P; ++p) red4[w * SYM_P + p][lane] = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+        __syncthreads();
+        float4 a = red4[w][lane];                                 // wave 0's sum of pair p = w
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const float4 b = red4[k * SYM_P + w][lane]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if constexpr (UM) { a.x *= um_mass; a.y *= um_mass; a.z *= um_mass; a.w *= um_mass; }
+        *reinterpret_cast<float4 *>(&out[w * 128u + 2u * lane]) = a;
+    } else {
+#pragma unroll
+        for (int p = 0; p < SYM_P; ++p) {
+            if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
+            *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+        }
     }
+}
+
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
+__global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
+void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
+                   const SymItem *__restrict__ items,
+                   float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
+                   uint32_t n, float eps2, float um_mass)
+{
+    force_sym_f32_body<RSQ, MM, PAIRS, WS>(pos, mass, sigma, items, slab_s, slab_r, n, eps2, um_mass);
 }
 
 // sigma[i] = m_i^(-1/2) for the mass-scaled kernels (correctly rounded sqrt and divide)
@@ -734,7 +783,7 @@ void mass_sigma(const float *__restrict__ mass, float *__restrict__ sigma, uint3
 // gather is the one HBM-bound kernel of the step), the 8 partials are then added in q order — a fixed association
 // whatever the launch, so results are reproducible run to run.
 constexpr int GATHER_Q = 8, GATHER_T = BLOCK / GATHER_Q, GATHER_V = 2, GATHER_P = GATHER_T * GATHER_V;
-static_assert(SYM_SB % GATHER_P == 0, "the particles of a gather workgroup share a tile");
+static_assert(SYM_SB % GATHER_P == 0 && SYM_SB_WS % GATHER_P == 0, "the particles of a gather workgroup share a tile");
 
 // two adjacent elements (element index even: 16-byte aligned for float2)
 __device__ __forceinline__ void load_pair(const float2 *__restrict__ p, float2 &a, float2 &b)
@@ -748,7 +797,8 @@ __device__ __forceinline__ void load_pair(const double2 *__restrict__ p, double2
 // block is everything; sharded ranks: the LATE local items' slabs on top of the reduce-scattered sum
 // `base`), saving the acc_sum round trip and a launch; otherwise it is stored to acc_sum (sharded ranks:
 // the partial of every particle, to be reduce-scattered).
-// The launch covers particles [k0, k0 + kn), k0 a multiple of the tile size; tile g's stationary rows are
+// The launch covers particles [k0, k0 + kn), k0 a multiple of the tile size 1 << sb_shift (2048, or 512 for the
+// wave-split plans); tile g's stationary rows are
 // [row_lo[g], row_hi[g]), its coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).  Segment bounds are
 // multiples of 64 (or n) and segment offsets even (nb_plan.cpp), so a pair (k, k + 1), k even, is covered together.
 template <typename real, bool FUSE>
@@ -764,7 +814,7 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
                 typename vec2_of<real>::type *__restrict__ pos_next,
                 typename vec2_of<real>::type *__restrict__ vel,
                 typename vec2_of<real>::type *__restrict__ acc,
-                real dt_kick, real dt_drift, int extras, int flags)
+                real dt_kick, real dt_drift, int extras, int flags, uint32_t sb_shift)
 {
     typedef typename vec2_of<real>::type real2;
     __shared__ real2 part[GATHER_Q][GATHER_P];
@@ -772,12 +822,12 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     const uint32_t li = blockIdx.x * GATHER_P + 2u * p, k = k0 + li;
     real2 a0, a1; a0.x = a0.y = a1.x = a1.y = 0;
     if (li < kn) {
-        const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
+        const uint32_t g = k >> sb_shift, loc = k & ((1u << sb_shift) - 1u);
         const uint32_t r0 = row_lo[g], r1 = row_hi[g];
 #pragma unroll 4      // four independent 16-byte loads in flight per thread; the adds keep their order
         for (uint32_t r = r0 + q; r < r1; r += GATHER_Q) {
             real2 b0, b1;
-            load_pair(slab_s + (size_t)r * SYM_SB + loc, b0, b1);        // rows are whole tiles: loc + 1 is inside
+            load_pair(slab_s + ((size_t)r << sb_shift) + loc, b0, b1);   // rows are whole tiles: loc + 1 is inside
             a0.x += b0.x; a0.y += b0.y; a1.x += b1.x; a1.y += b1.y;
         }
         const uint32_t c1 = cov_begin[g + 1];

@@ -18,13 +18,13 @@ namespace nbk {
 
 namespace {
 struct Geometry {
-    uint32_t n, world, tiles, chunks, cpt, tpb;
-    Geometry(uint32_t n_, uint32_t world_) : n(n_), world(world_ ? world_ : 1)
+    uint32_t n, world, sb, tiles, chunks, cpt, tpb;
+    Geometry(uint32_t n_, uint32_t world_, uint32_t sb_) : n(n_), world(world_ ? world_ : 1), sb(sb_ ? sb_ : SYM_SB)
     {
-        tiles = (n + SYM_SB - 1) / SYM_SB;
+        tiles = (n + sb - 1) / sb;
         chunks = (n + SYM_CH - 1) / SYM_CH;
-        cpt = SYM_SB / SYM_CH;
-        tpb = world > 1 ? (n / world) / SYM_SB : tiles;      // tiles per block
+        cpt = sb / SYM_CH;
+        tpb = world > 1 ? (n / world) / sb : tiles;          // tiles per block
         if (tpb == 0) tpb = 1;
     }
     uint32_t block_of(uint32_t I) const { return I / tpb; }
@@ -37,9 +37,9 @@ struct Geometry {
 };
 }  // namespace
 
-void sym_units(uint32_t n, uint32_t world, uint64_t *local_sym_units, uint64_t *cross_total)
+void sym_units(uint32_t n, uint32_t world, uint64_t *local_sym_units, uint64_t *cross_total, uint32_t sb)
 {
-    const Geometry g(n, world);
+    const Geometry g(n, world, sb);
     uint64_t local_max = 0, cross = 0;
     std::vector<uint64_t> local_of(g.world, 0);
     for (uint32_t I = 0; I < g.tiles; ++I) {
@@ -53,18 +53,18 @@ void sym_units(uint32_t n, uint32_t world, uint64_t *local_sym_units, uint64_t *
     if (cross_total) *cross_total = cross;
 }
 
-uint64_t sym_slab_r_bound(uint32_t n, uint32_t world)
+uint64_t sym_slab_r_bound(uint32_t n, uint32_t world, uint32_t sb)
 {
     uint64_t local = 0, cross = 0;
-    sym_units(n, world, &local, &cross);
+    sym_units(n, world, &local, &cross, sb);
     const uint64_t w = world ? world : 1;
     // a rank's cross run is cut at item boundaries: at most one item (<= one tile row of chunks) over its share
-    return (local + (cross + w - 1) / w + (uint64_t)(n / SYM_CH) + SYM_SB / SYM_CH) * SYM_CH;
+    return (local + (cross + w - 1) / w + (uint64_t)(n / SYM_CH) + (sb ? sb : SYM_SB) / SYM_CH) * SYM_CH;
 }
 
 void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, const SymTuning &tune, SymPlan &pl)
 {
-    const Geometry g(n, world);
+    const Geometry g(n, world, tune.sb);
     world = g.world;
     const uint32_t tiles = g.tiles, chunks = g.chunks;
     if (cus < 1) cus = 1;
@@ -95,7 +95,9 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         L = fill > grain ? fill : grain;
     }
     if (L < 1) L = 1;
-    if (tune.even_chunks && !tune.forced_L) L = L < 2 ? 2u : (L & ~1u);   // chunk pairs (a forced L is taken as given)
+    // chunk pairs: even counts; wave-split tiles: one chunk (pair) per wave, i.e. multiples of 4 (8) — a forced L is taken as given
+    const uint32_t unit = tune.quantum();
+    if (unit > 1 && !tune.forced_L) L = L < unit ? unit : ((L + unit / 2) / unit) * unit;
 
     // Cross items: EVERY tile's range of later-block chunks [be, chunks) is cut into `world` contiguous sub-ranges and
     // rank r takes sub-range (r + I) mod world of tile I.  Every rank therefore holds a slice of every tile: its stationary
@@ -106,7 +108,6 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // over the ranks.  Units are chunk pairs for handles that sweep pairs (even_chunks).
     std::vector<SymItem> local_items, cross_items, late_items;
     std::vector<uint32_t> local_rows_of(tiles, 0), cross_rows_of(tiles, 0), late_rows_of(tiles, 0);
-    const uint32_t unit = tune.even_chunks ? 2u : 1u;
     for (uint32_t I = 0; I < tiles; ++I) {
         const uint32_t be = g.block_end_chunk(I);
         if (g.block_of(I) == rank || world == 1) {
@@ -168,7 +169,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
                 const double f = total ? (double)done / (double)total : 0.0;
                 const uint32_t div = f < tune.tail_at[0] ? 1u : f < tune.tail_at[1] ? 2u : f < tune.tail_at[2] ? 4u : 8u;
                 uint32_t piece = (L + div - 1) / div;
-                if (tune.even_chunks) piece = (piece + 1u) & ~1u;
+                piece = ((piece + unit - 1) / unit) * unit;
                 done += it.cnt;
                 if (div == 1 || it.cnt <= piece) { out.push_back(it); continue; }
                 --rows_of[it.tile];
@@ -238,6 +239,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     pl.items.insert(pl.items.end(), late_items.begin(), late_items.end());
     pl.L = L;
     pl.tiles = tiles;
+    pl.sb = g.sb;
 
     // Gather lists: for every tile the segments that hold partials of (some of) its particles, in segment
     // order — sym_gather reads slab_r[base + k] for each entry with lo <= k < hi: no scan over the segments
@@ -246,14 +248,14 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         begin.assign((size_t)tiles + 1, 0);
         for (size_t s = s0; s < s1; ++s) {
             const SymSeg &sg = pl.segs[s];
-            for (uint32_t t = sg.lo / SYM_SB; t <= (sg.hi - 1) / SYM_SB; ++t) ++begin[t + 1];
+            for (uint32_t t = sg.lo / g.sb; t <= (sg.hi - 1) / g.sb; ++t) ++begin[t + 1];
         }
         for (uint32_t t = 0; t < tiles; ++t) begin[t + 1] += begin[t];
         cov.assign(begin[tiles], SymCov{0, 0u, 0u});
         std::vector<uint32_t> fill(begin.begin(), begin.end() - 1);
         for (size_t s = s0; s < s1; ++s) {
             const SymSeg &sg = pl.segs[s];
-            for (uint32_t t = sg.lo / SYM_SB; t <= (sg.hi - 1) / SYM_SB; ++t)
+            for (uint32_t t = sg.lo / g.sb; t <= (sg.hi - 1) / g.sb; ++t)
                 cov[fill[t]++] = SymCov{(int64_t)sg.off - (int64_t)sg.lo, sg.lo, sg.hi};
         }
     };

@@ -14,11 +14,13 @@
 
 namespace nbk {
 
-constexpr uint32_t SYM_SB = 2048;   // stationary particles per workgroup / block-tile
+constexpr uint32_t SYM_SB = 2048;   // stationary particles per workgroup / block-tile (4 waves x 512 different particles)
+constexpr uint32_t SYM_SB_WS = 512; // block-tile of the WAVE-SPLIT kernels (small and mid-size systems): the 4 waves of a workgroup
+                                    // hold the SAME 512 stationary particles and sweep DIFFERENT chunks of the item
 constexpr uint32_t SYM_CH = 64;     // travelling chunk (one particle per lane of a wave64)
 
-// One workgroup of force_sym_*: tile `tile` against chunks [c0, c0 + cnt).
-//   s_row    row of slab_s (2048 elements each) receiving the stationary partial of the item
+// One workgroup of force_sym_*: tile `tile` (SymPlan::sb particles) against chunks [c0, c0 + cnt).
+//   s_row    row of slab_s (sb elements each) receiving the stationary partial of the item
 //   r_base   element offset into slab_r such that the travelling partial of particle j goes to
 //            slab_r[r_base + j] (the item's segment starts at particle seg.lo: r_base = seg.off - seg.lo,
 //            which can be negative)
@@ -44,12 +46,15 @@ struct SymTuning {
     bool guided_tail = true;      // finer items at the end of each launch
     bool even_chunks = false;     // cut items into EVEN chunk counts: the fp32 2-D kernel sweeps chunk PAIRS (sym_chunks2), and
                                   // an odd item wastes half a pair
+    uint32_t sb = SYM_SB;         // particles per block-tile: SYM_SB, or SYM_SB_WS for the wave-split kernels, whose items are
+                                  // cut into multiples of 4 chunks (one per wave; 8 with chunk pairs) — see quantum()
+    uint32_t quantum() const { return (sb == SYM_SB_WS ? 4u : 1u) * (even_chunks ? 2u : 1u); }
     double tail_at[3] = {0.85, 0.94, 0.98};
 };
 
 struct SymPlan {
     std::vector<SymItem> items;                 // [local | cross | late]
-    uint32_t n_local = 0, n_cross = 0, n_late = 0, L = 0, tiles = 0;
+    uint32_t n_local = 0, n_cross = 0, n_late = 0, L = 0, tiles = 0, sb = SYM_SB;
     std::vector<uint32_t> rowbase, rowmid;      // stationary rows of tile g: [rowbase[g], rowmid[g]) local + cross,
                                                 // [rowmid[g], rowbase[g + 1]) late
     std::vector<SymSeg> segs;                   // nsegs_main segments of local + cross first, then the late ones
@@ -64,10 +69,10 @@ struct SymPlan {
 // Rank-independent size figures of a symmetric plan (every rank of a run must take the same decisions).
 //   local_sym_units   (tile, chunk) units of one block's internal symmetric items
 //   cross_total       (tile, chunk) units between different blocks, all ranks together
-void sym_units(uint32_t n, uint32_t world, uint64_t *local_sym_units, uint64_t *cross_total);
+void sym_units(uint32_t n, uint32_t world, uint64_t *local_sym_units, uint64_t *cross_total, uint32_t sb = SYM_SB);
 
 // Upper bound, equal on all ranks, of the slab_r elements one handle of the run needs.
-uint64_t sym_slab_r_bound(uint32_t n, uint32_t world);
+uint64_t sym_slab_r_bound(uint32_t n, uint32_t world, uint32_t sb = SYM_SB);
 
 void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, const SymTuning &tune, SymPlan &pl);
 

@@ -64,6 +64,7 @@ class Simulation:
         shard_single: bool = False,
         mass_scaling: bool = False,
         sym_chunk_pairs: int = 0,
+        sym_tile: int = 0,
     ):
         """The last eight arguments are ``nb_params.flags`` and the launch-geometry tuning fields
         (0 / True = the library's automatic choice); the library reads no environment variables."""
@@ -98,6 +99,7 @@ class Simulation:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail
         p.first_frame = first_frame
         p.sym_chunk_pairs = sym_chunk_pairs
+        p.sym_tile = sym_tile
         p.shard_rank, p.shard_world = shard_rank, shard_world
         if acc_buffers is not None:
             p.acc_buffers[0], p.acc_buffers[1] = acc_buffers

@@ -133,7 +133,8 @@ def _sym_worker(rank, world, port, n, steps, out_dir):
             slab_r[:] = np.nan                                          # every element must be written before it is read
             for it in items:
                 tile, c0, c, diag, r_base = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"]), int(it["r_base"])
-                S = slice(tile * 2048, min((tile + 1) * 2048, n))
+                sb = info["tile_particles"]
+                S = slice(tile * sb, min((tile + 1) * sb, n))
                 T = slice(c0 * 64, min((c0 + c) * 64, n))
                 d = x[None, T, :] - x[S, None, :]                       # r = p_j - p_i (Quadtree.hpp:136)
                 inv3 = (d[..., 0] ** 2 + d[..., 1] ** 2 + eps2) ** -1.5
@@ -248,7 +249,8 @@ def _allreduce_worker(rank, world, port, n, steps, out_dir):
             acc = np.zeros((n, 2))
             for it in items:
                 tile, c0, c, diag = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"])
-                S = slice(tile * 2048, min((tile + 1) * 2048, n))
+                sb = info["tile_particles"]
+                S = slice(tile * sb, min((tile + 1) * sb, n))
                 T = slice(c0 * 64, min((c0 + c) * 64, n))
                 d = x[None, T, :] - x[S, None, :]
                 inv3 = (d[..., 0] ** 2 + d[..., 1] ** 2 + eps2) ** -1.5

@@ -1,6 +1,6 @@
 """CPU: the symmetric kernel's host-side work planner (nb_debug_sym_plan, nbodysim_amd/csrc/nb_plan.cpp).
 The 8-GPU partition cannot be run in this container, so its correctness is checked by construction: over all
-ranks, every unordered pair of (2048-particle tile, 64-particle chunk) is covered exactly once — diagonal
+ranks, every unordered pair of (2048- or 512-particle tile, 64-particle chunk) is covered exactly once — diagonal
 items cover a tile's own chunks, symmetric items the chunks after it — stationary slab rows are unique, the
 travelling-slab ranges the items write are disjoint and fill the (triangular) slab exactly, and the ranks'
 work is balanced."""
@@ -44,18 +44,24 @@ def check_slab_ranges(items, info, n, esz=8):
     assert total <= units * CH + len(lo) and total > (units - len(set(sym["tile"]))) * CH      # = 64 per unit, ragged last chunk aside
 
 
-@pytest.mark.parametrize("n,world", [(16384, 1), (20000, 1), (70001, 1), (262144, 1), (262144, 2), (262144, 4), (262144, 8),
-                                     (65536, 8), (1048576, 8), (196608, 3)])
-def test_items_cover_every_tile_chunk_pair_exactly_once(n, world):
+@pytest.mark.parametrize("n,world,tile", [(16384, 1, 0), (20000, 1, 0), (25000, 1, 512), (25000, 1, 2048), (70001, 1, 0), (70001, 1, 2048),
+                                          (262144, 1, 0), (131072, 1, 512), (262144, 2, 0), (262144, 4, 0), (262144, 8, 0),
+                                          (65536, 8, 0), (1048576, 8, 0), (196608, 3, 0)])
+def test_items_cover_every_tile_chunk_pair_exactly_once(n, world, tile):
+    """tile = 0: the library's choice (wave-split tiles of 512 for single handles below 49 152 bodies, else 2048)."""
+    tuning = {"sym_tile": tile} if tile else {}
+    SB = plan(n, 0, world, **tuning)[1]["tile_particles"]
+    assert SB == (tile or (512 if world == 1 and n < 49152 else 2048))
+    quantum = (4 if SB == 512 else 1) * (2 if n >= 65536 else 1)       # chunks per item come in multiples of this
     tiles, chunks, cpt = -(-n // SB), -(-n // CH), SB // CH
     cover = np.zeros((tiles, chunks), np.int32)
     work = []
     blk_tiles = tiles if world == 1 else (n // world) // SB
     cross_totals = set()
     for rank in range(world):
-        items, info = plan(n, rank, world)
+        items, info = plan(n, rank, world, **tuning)
         nloc, Lc = info["items_local"], info["chunks_per_item"]
-        assert len(items) == info["items"] > 0 and Lc >= 1 and 0 < nloc <= len(items)
+        assert len(items) == info["items"] > 0 and Lc >= 1 and 0 < nloc <= len(items) and Lc % quantum == 0
         assert info["items_local"] + info["items_cross"] + info["items_late"] == info["items"]
         assert info["tiles"] == tiles and info["rows_s"] == len(items)
         cross_totals.add(info["cross_units_total"])
@@ -141,7 +147,7 @@ def test_tuning_fields_replace_the_environment_switches():
 
 
 def test_plan_fills_the_chip():
-    for n, world, lo, hi in ((262144, 1, 5000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 1400)):
+    for n, world, lo, hi in ((262144, 1, 5000, 14000), (262144, 8, 3000, 6000), (16384, 1, 500, 2400)):
         items, info = plan(n, world // 2, world)
         assert lo <= len(items) <= hi, (n, world, len(items), info["chunks_per_item"])
 

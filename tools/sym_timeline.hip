@@ -1,0 +1,136 @@
+// tools/sym_timeline.hip — where does a short launch of the symmetric kernel lose its time?  (not part of the product)
+//
+// Runs the PRODUCT kernel body (force_sym_f32_body from nbodysim_amd/csrc/nb_kernels.hip.h) over the PRODUCT plan
+// (nb_plan.cpp) inside a wrapper that stamps, per workgroup, start / end in the 100 MHz real-time counter and in shader
+// clocks, and the XCC / SE / CU it ran on.  Prints: launch wall time (HIP events), shader clock during the launch,
+// the ideal time of the plan's VALU work at that clock, the dispatch ramp (first / last workgroup start), workgroup
+// durations, the busiest and the idlest CU (sum of its workgroups' VALU work), and the drain (time from the median
+// workgroup end to the last one).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Inbodysim_amd/csrc -Iinclude -o build/sym_timeline tools/sym_timeline.hip nbodysim_amd/csrc/nb_plan.cpp
+//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [general=1] [pairs=0] [reps=20]
+#include "nb_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <random>
+#include <vector>
+
+using namespace nbk;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
+
+struct Stamp { unsigned long long t0, t1, c0, c1; unsigned hw_id, xcc_id; };
+
+template <int MM, bool PAIRS, bool WS>
+__global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
+void stamped(const float2 *pos, const float *mass, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items, slab_s, slab_r, n, eps2, um);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        Stamp s;
+        s.t0 = t0; s.t1 = t1; s.c0 = c0; s.c1 = c1;
+        s.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        s.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        st[blockIdx.x] = s;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 25000u;
+    const uint32_t tile = argc > 2 ? (uint32_t)atoi(argv[2]) : 512u;
+    const uint32_t L = argc > 3 ? (uint32_t)atoi(argv[3]) : 0u;
+    const bool general = argc > 4 ? atoi(argv[4]) != 0 : true;
+    const bool pairs = argc > 5 ? atoi(argv[5]) != 0 : false;
+    const int reps = argc > 6 ? atoi(argv[6]) : 20;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+
+    SymTuning t; t.sb = tile; t.forced_L = L; t.even_chunks = pairs;
+    SymPlan pl; build_sym_plan(n, (uint32_t)cus, 0, 1, t, pl);
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    std::vector<float2> hp(n); std::vector<float> hm(n);
+    for (uint32_t i = 0; i < n; ++i) { hp[i] = make_float2(U(rng), U(rng)); hm[i] = general ? 0.5f + 0.5f * std::fabs(U(rng)) : 1.0f / n; }
+    float2 *pos, *ss, *sr; float *mass; SymItem *items; Stamp *st;
+    const size_t rows = pl.rowbase[pl.tiles];
+    CK(hipMalloc(&pos, n * sizeof(float2))); CK(hipMalloc(&mass, n * sizeof(float)));
+    CK(hipMalloc(&ss, rows * tile * sizeof(float2))); CK(hipMalloc(&sr, (pl.slab_r_elems + 2) * sizeof(float2)));
+    CK(hipMalloc(&items, pl.items.size() * sizeof(SymItem))); CK(hipMalloc(&st, pl.items.size() * sizeof(Stamp)));
+    CK(hipMemcpy(pos, hp.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+    CK(hipMemcpy(mass, hm.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(items, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
+    const uint32_t grid = (uint32_t)pl.items.size();
+    const float eps2 = 1e-4f, um = 1.0f / n;
+    auto launch = [&]() {
+#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid, BLOCK>>>(pos, mass, items, ss, sr, n, eps2, um, st)
+        if (tile == SYM_SB_WS) { if (general) { if (pairs) GO(MM_GENERAL, true, true); else GO(MM_GENERAL, false, true); }
+                                 else         { if (pairs) GO(MM_UNIFORM, true, true); else GO(MM_UNIFORM, false, true); } }
+        else                   { if (general) { if (pairs) GO(MM_GENERAL, true, false); else GO(MM_GENERAL, false, false); }
+                                 else         { if (pairs) GO(MM_UNIFORM, true, false); else GO(MM_UNIFORM, false, false); } }
+#undef GO
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int k = 0; k < 50; ++k) launch();              // warm the clocks
+    CK(hipDeviceSynchronize());
+    std::vector<float> wall;
+    for (int k = 0; k < reps; ++k) {
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); wall.push_back(ms * 1e3f);
+    }
+    // back-to-back rate (what a step loop sees)
+    CK(hipEventRecord(e0)); for (int k = 0; k < 200; ++k) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms200; CK(hipEventElapsedTime(&ms200, e0, e1));
+    std::sort(wall.begin(), wall.end());
+    std::vector<Stamp> hs(grid);
+    CK(hipMemcpy(hs.data(), st, grid * sizeof(Stamp), hipMemcpyDeviceToHost));
+
+    // VALU cycles of the plan: a symmetric body (2 stationary x 1 travelling, both directions) = 10 packed (12 with masses) x 4 + 2 x 8
+    // cycles; a diagonal one 8 (9) x 4 + 16; a wave runs 4 bodies per rotation step, 64 steps per chunk
+    const double cyc_sym = (general ? 12 : 10) * 4 + 16, cyc_diag = (general ? 9 : 8) * 4 + 16;
+    double work = 0;                                        // SIMD cycles of the whole launch
+    std::vector<double> item_cyc(grid);
+    for (uint32_t i = 0; i < grid; ++i) {
+        const SymItem &it = pl.items[i];
+        const double per_chunk_wave = 64.0 * 4.0 * (it.diag ? cyc_diag : cyc_sym);
+        // classic: 4 waves each sweep every chunk of the item; wave-split: the chunks are shared out
+        item_cyc[i] = per_chunk_wave * it.cnt * (tile == SYM_SB_WS ? 1.0 : 4.0);
+        work += item_cyc[i];
+    }
+    unsigned long long tmin = ~0ull, tmax = 0, last_start = 0;
+    double clk_sum = 0; size_t clk_n = 0;
+    std::vector<double> dur, ends, starts;
+    std::map<unsigned, double> cu_work; std::map<unsigned, int> cu_items;
+    for (uint32_t i = 0; i < grid; ++i) {
+        const Stamp &s = hs[i];
+        tmin = std::min(tmin, s.t0); tmax = std::max(tmax, s.t1); last_start = std::max(last_start, s.t0);
+        if (s.t1 > s.t0 + 100) { clk_sum += (double)(s.c1 - s.c0) / (double)(s.t1 - s.t0) * 100.0; ++clk_n; }   // MHz
+        const unsigned cu = (s.xcc_id & 0xf) << 16 | ((s.hw_id >> 13) & 0x7) << 8 | ((s.hw_id >> 8) & 0xf);      // xcc | se | cu
+        cu_work[cu] += item_cyc[i]; cu_items[cu] += 1;
+    }
+    for (uint32_t i = 0; i < grid; ++i) { dur.push_back((hs[i].t1 - hs[i].t0) * 0.01); ends.push_back((hs[i].t1 - tmin) * 0.01); starts.push_back((hs[i].t0 - tmin) * 0.01); }
+    std::sort(dur.begin(), dur.end()); std::sort(ends.begin(), ends.end()); std::sort(starts.begin(), starts.end());
+    const double mhz = clk_n ? clk_sum / clk_n : 0.0;
+    const double simds = 4.0 * cus;
+    const double ideal_us = work / simds / (mhz > 0 ? mhz : 2400.0);
+    double wmax = 0, wmin = 1e300; for (auto &kv : cu_work) { wmax = std::max(wmax, kv.second); wmin = std::min(wmin, kv.second); }
+    int imax = 0, imin = 1 << 30; for (auto &kv : cu_items) { imax = std::max(imax, kv.second); imin = std::min(imin, kv.second); }
+    printf("n=%u tile=%u L=%u general=%d pairs=%d | items=%u rows=%zu | CUs=%d seen=%zu\n", n, tile, pl.L, (int)general, (int)pairs, grid, rows, cus, cu_work.size());
+    printf("  launch wall (events): min %.1f median %.1f us | back-to-back %.1f us per launch\n", wall.front(), wall[wall.size() / 2], ms200 * 1e3 / 200);
+    printf("  shader clock during the workgroups: %.0f MHz | VALU work of the plan at that clock on %d SIMDs: %.1f us (%.1f at 2400 MHz)\n",
+           mhz, (int)simds, ideal_us, work / simds / 2400.0);
+    printf("  inside the kernel: first start -> last end %.1f us | last workgroup START at %.1f us (90%% started by %.1f)\n",
+           (tmax - tmin) * 0.01, (last_start - tmin) * 0.01, starts[(size_t)(0.9 * grid)]);
+    printf("  workgroup duration: min %.1f median %.1f p90 %.1f max %.1f us\n", dur.front(), dur[grid / 2], dur[(size_t)(0.9 * grid)], dur.back());
+    printf("  workgroup ends: 10%% %.1f median %.1f 90%% %.1f last %.1f us\n", ends[(size_t)(0.1 * grid)], ends[grid / 2], ends[(size_t)(0.9 * grid)], ends.back());
+    printf("  per CU: items min %d max %d | VALU work max / mean = %.3f, min / mean = %.3f -> busiest CU alone needs %.1f us at that clock\n",
+           imin, imax, wmax / (work / cu_work.size()), wmin / (work / cu_work.size()), wmax / 4.0 / (mhz > 0 ? mhz : 2400.0));
+    return 0;
+}
