@@ -148,13 +148,34 @@ class DeviceSampler:
         return out
 
 
-def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler_period=0.02, adaptive=True):
+def sustained_steps(ms_per_step_hint, min_seconds=2.0):
+    """Steps of the sustained stretch for a step time of `ms_per_step_hint`: a pure function — every rank must feed it the SAME hint."""
+    return max(20, int(min_seconds * 1e3 / max(ms_per_step_hint, 1e-3)) + 1)
+
+
+def reduce_max_over_ranks(value, world):
+    """MAX of a host float over the ranks of the default process group (the identity for one rank)."""
+    if world <= 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler_period=0.02, world=1, reduce_max=reduce_max_over_ranks):
     """The settled rate: at least `min_seconds` of back-to-back steps AFTER the driver's timed region (whose 20 steps
-    sit before the power controller has settled), with the device clock / power of exactly that stretch.  Single GPU
-    (`adaptive`): if the first batch — sized from the timed region's rate — ends early, further batches sized from the
-    rate measured so far follow until the stretch is long enough; with several ranks the one batch is sized from the
-    MAX-reduced time, so that every rank enqueues the same number of steps."""
-    steps = max(20, int(min_seconds * 1e3 / max(ms_per_step_hint, 1e-3)) + 1)
+    sit before the power controller has settled), with the device clock / power of exactly that stretch.  Single GPU:
+    if the first batch — sized from the timed region's rate — ends early, further batches sized from the rate measured
+    so far follow until the stretch is long enough.
+    SEVERAL RANKS: every step is a set of collectives, so every rank must enqueue the SAME number of steps.  Nothing
+    rank-local may decide that number: the hint is MAX-reduced over the ranks HERE (whatever the caller passed), there
+    is exactly one batch, and no measured time feeds back into a step count (round 3 lost a GPU call to exactly that:
+    step counts sized from each rank's own clock -> mismatched collective counts -> deadlock)."""
+    adaptive = world <= 1
+    steps = sustained_steps(reduce_max(ms_per_step_hint, world), min_seconds)
     smp = DeviceSampler(period_s=sampler_period)
     smp.start()
     t0 = time.perf_counter()
@@ -248,10 +269,16 @@ def main() -> None:
                     help="multi-GPU exchange: tune (default) times a few steps of the symmetric pair split (reduce-scatter + "
                          "all-gather) and of north_star's all-gather protocol before the timed region and keeps the faster; "
                          "the others force one")
-    ap.add_argument("--driver", default="tune", choices=["tune", "torch", "c"],
-                    help="multi-GPU step loop: torch = collectives through torch.distributed between the library's split-step calls; "
-                         "c = the library's own RCCL loop (nb_comm_step: one foreign call for all steps); tune (default) = both are "
-                         "candidates of the start-up timing")
+    ap.add_argument("--driver", default="torch", choices=["tune", "torch", "c"],
+                    help="multi-GPU step loop: torch (default) = collectives through torch.distributed between the library's split-step "
+                         "calls; c = the library's own RCCL loop (nb_comm_step: one foreign call for all steps; it has run with ONE real "
+                         "rank and, multi-rank, over the test-only loopback transport — never with two ranks over RCCL, so it is "
+                         "not the default of a first run on a node); tune = both are candidates of the start-up timing")
+    ap.add_argument("--deadline", type=float, default=900.0,
+                    help="seconds the whole multi-GPU run may take before the rank prints the phase it is in and exits with status 3 "
+                         "(a stuck collective must not become a silent hang); 0 = none")
+    ap.add_argument("--candidate-deadline", type=float, default=120.0,
+                    help="seconds one start-up candidate (or forming the C-level communicator) may take before the same")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s settled-rate measurement after the timed region")
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
@@ -288,11 +315,22 @@ def main() -> None:
         import torch.distributed as dist
         from nbodysim_amd.dist import DistributedSimulation
 
+        import datetime
+
+        from nbodysim_amd.dist import Watchdog
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # no wait without an end: the process group's own collective timeout (its watchdog aborts the process) and, around the
+        # whole run, a wall-clock deadline that names the phase the rank was in
+        phase = {"now": "forming the process group"}
+        main_watchdog = Watchdog(args.deadline, "running bench.py", report=lambda: f"phase: {phase['now']}", rank=rank)
+        main_watchdog.__enter__()
+        pg_timeout = datetime.timedelta(seconds=max(60.0, min(600.0, args.deadline or 600.0)))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
+        phase["now"] = "first collectives (communicator bring-up)"
         # bring the communicator up (channels, RCCL kernels) before anything is tuned or timed, whatever --warmup is
         scratch = torch.zeros((world * 64, 2), dtype=torch.float32, device="cuda")
         dist.all_gather_into_tensor(scratch, scratch[rank * 64:(rank + 1) * 64])
@@ -302,16 +340,19 @@ def main() -> None:
         torch.cuda.synchronize()
         if args.no_symmetry and args.protocol not in ("tune", "allgather"):
             raise SystemExit("--no-symmetry with several ranks means the all-gather protocol")
+        phase["now"] = f"creating the sharded simulation (protocol {args.protocol}, driver {args.driver})"
         sim = DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank,
                                     protocol="allgather" if args.no_symmetry else args.protocol, tune_dt=DT,
-                                    driver=args.driver if args.backend == "nccl" else "torch",
+                                    driver=args.driver if args.backend == "nccl" else "torch", deadline_s=args.candidate_deadline,
                                     uniform_mass=not args.general_mass, dims=args.dims, sym_chunks_per_item=args.chunks_per_item)
         inner = sim.sim
         advance, wait = sim.advance, sim.wait
 
         def barrier():
             dist.barrier()
+        phase["now"] = "warm-up and timed region"
     else:
+        phase, main_watchdog = {"now": ""}, None
         sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
                             symmetry=not args.no_symmetry, uniform_mass=not args.general_mass, sym_chunks_per_item=args.chunks_per_item)
         inner = sim
@@ -346,9 +387,7 @@ def main() -> None:
     phases = sim.phase_report() if (world > 1 and not args.no_kernel_events) else None
     k1, u1 = sim.energy()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        elapsed = reduce_max_over_ranks(elapsed, world)
         if phases is not None:   # slowest rank per phase, so an exposed collective on any rank shows
             keys = [k for k, v in phases.items() if isinstance(v, float)]
             pt = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device="cuda")
@@ -364,9 +403,9 @@ def main() -> None:
         events = world == 1 and not args.no_kernel_events       # per-launch events on the single-GPU path only (nb_step bounds their number)
         if events:
             inner.profile(True)
+        phase["now"] = "sustained stretch"
         barrier()
-        sustained = sustained_rate(advance, wait, DT, elapsed / max(1, args.steps) * 1e3, sampler_period=0.02 if world == 1 else 0.1,
-                                   adaptive=world == 1)
+        sustained = sustained_rate(advance, wait, DT, elapsed / max(1, args.steps) * 1e3, sampler_period=0.02 if world == 1 else 0.1, world=world)
         barrier()
         if events:
             sms, sl = inner.profile_read()
@@ -374,9 +413,7 @@ def main() -> None:
             if sl:
                 sustained["avg_launch_ms"] = sms / sl
         if world > 1:
-            t = torch.tensor([sustained["seconds"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sustained["seconds"] = float(t[0])
+            sustained["seconds"] = reduce_max_over_ranks(sustained["seconds"], world)
             sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
 
     # secondary figure, outside the timed region and not part of `value`: the same kernel without the equal-mass
@@ -435,9 +472,10 @@ def main() -> None:
         # pair once for both particles, the diagonal items and the one-sided kernel every ordered pair
         ex = EXECUTED[(args.precision, args.dims)]
         if symmetric and world == 1:
-            diag_units = info["tiles"] * 32.0
+            tile = float(info.get("tile_particles") or 2048)        # 2048 (classic) or 512 (wave-split kernels) stationary particles per item
+            diag_units = info["tiles"] * tile / 64.0                 # every tile meets its own chunks one-sidedly
             sym_units = info["units_local"] + info["units_cross"] + info["units_late"] - diag_units
-            exec_flop = (sym_units * ex["sym"][0 if um else 1] + diag_units * ex["one"][0 if um else 1]) * 2048.0 * 64.0
+            exec_flop = (sym_units * ex["sym"][0 if um else 1] + diag_units * ex["one"][0 if um else 1]) * tile * 64.0
         elif world == 1:
             exec_flop = ex["one"][0 if um else 1] * pairs_per_step
         else:
@@ -559,9 +597,11 @@ def main() -> None:
                                                "N=262144 in the survey container (8 vCPU Xeon), not on this box; never mixed into pair interactions/s")
         print(json.dumps(line), flush=True)
 
+    phase["now"] = "closing"
     sim.close()
     if world > 1:
         dist.destroy_process_group()
+        main_watchdog.__exit__(None, None, None)
 
 
 if __name__ == "__main__":

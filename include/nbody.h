@@ -166,6 +166,10 @@ typedef struct nb_params {
                                      particles and split the item's chunks: finer work units and 4-KiB slab rows for small and
                                      mid-size systems, 4x the travelling partials per pair); 0 = automatic (512 below 49 152 bodies) */
     int32_t  _reserved0;          /* keeps sizeof(nb_params) a multiple of 8 whatever the compiler; must be 0 */
+    uint64_t pos_rows;            /* rows (particles) each caller-owned pos_buffers[] holds; 0 = n.  A sharded run whose world size does
+                                     not divide n all-gathers ceil(n / world) rows per rank, so its replicas need world * ceil(n / world)
+                                     rows: replicas the library allocates itself are sized that way, caller-owned ones must be and say so
+                                     here (rows past n are never read by the kernels) */
 } nb_params;
 
 typedef struct nb_sim nb_sim; /* opaque; stands for one `Simulation` (Simulation.hpp:49) */
@@ -329,6 +333,7 @@ int   nb_step_begin(nb_sim *s, float dt);
 int   nb_step_mid(nb_sim *s);      /* NB_SHARD_SYMMETRIC only (no-op otherwise): see below */
 int   nb_step_finish(nb_sim *s);
 void *nb_pos_buffer(nb_sim *s, int which);   /* device pointer, n*(x,y) reals */
+size_t nb_pos_rows(const nb_sim *s);         /* rows each position replica holds: >= n (padded to world * ceil(n / world) for a sharded handle) */
 void *nb_stream(nb_sim *s);                  /* hipStream_t in use */
 
 /* Element layout of the device buffers above: positions / accelerations are `reals_per_element` reals per particle
@@ -350,12 +355,16 @@ int   nb_shard_rank(const nb_sim *s, int *world);   /* nb_params.shard_rank (and
  *   nb_comm_create_rank  one process per GPU (ncclCommInitRank): rank 0 calls nb_comm_unique_id and hands the
  *                        NB_COMM_ID_BYTES to the other ranks out of band (a file, MPI, a torch.distributed broadcast).
  * Handles: created with shard_rank / shard_world, rank r owning the block [r n/world, +n/world) (equal blocks, which
- * the in-place all-gather and the reduce-scatter need), or all n particles for NB_SHARD_ALLREDUCE; an unsharded
+ * the in-place all-gather and the reduce-scatter need; in the all-gather protocol world need not divide n: blocks of
+ * ceil(n / world) particles, the last one shorter, equal counts moved over padded replicas — nb_params.pos_rows),
+ * or all n particles for NB_SHARD_ALLREDUCE; an unsharded
  * handle forms a communicator of one rank (its all-gather is RCCL's one-rank no-op).  RCCL is loaded at first use
  * (librccl.so.1); without it nb_comm_create_* fail with NB_ENODEVICE — there is no other transport behind this API.
  * Like a handle, an nb_comm is driven by ONE thread, and its handles must outlive it (nb_comm_destroy first).  Between
  * nb_comm_step calls the handles may be read (nb_comm_flush, then nb_sync / nb_energy / nb_momentum) but not stepped by
- * other means.  If a call fails half-way through a step (a HIP or RCCL error), the run cannot be continued: destroy the
+ * other means.  If a call fails half-way through a step (a HIP or RCCL error), the run cannot be continued: the communicator is
+ * marked failed (an open ncclGroup is closed, further nb_comm_step / _flush / _wait return NB_ESTATE) and nb_comm_destroy
+ * then ABORTS the RCCL communicator (ncclCommAbort) instead of synchronising with peers that may never arrive; destroy the
  * communicator and the handles. */
 typedef struct nb_comm nb_comm;
 #define NB_COMM_ID_BYTES 128
@@ -371,6 +380,32 @@ int      nb_comm_flush(nb_comm *c);
 int      nb_comm_wait(nb_comm *c);
 void     nb_comm_destroy(nb_comm *c);        /* waits; the handles stay valid and are destroyed by their owner */
 int      nb_comm_info(const nb_comm *c, int *protocol, int *world, int *local_handles, int *rccl_version);
+/* NB_OK iff the transport (librccl) can be loaded in this process; every rank of a one-process-per-GPU job checks this, and
+ * the ranks agree on the answer, BEFORE any of them enters the blocking communicator formation of nb_comm_create_rank. */
+int      nb_comm_available(int *rccl_version);
+/* Per-phase timing inside the library's loop (attribution of a sharded step when no Python driver is around to time it):
+ * with profiling on, HIP events are recorded on each handle's COMPUTE stream around every compute-stream operation of the
+ * schedule; nb_comm_phase_read returns, for local handle `handle`, the milliseconds summed over the steps since the last
+ * reset — as the compute stream sees them, waits for the collectives included:
+ *   NB_PH_LOCAL    nb_step_begin: pairs inside the own block / local j-block / (all-reduce protocol) all of the rank's pairs
+ *   NB_PH_AG_WAIT  waiting for the all-gather of the previous step
+ *   NB_PH_CROSS    nb_step_mid: the rank's cross-block pairs + gather of the slabs (symmetric protocol)
+ *   NB_PH_REDUCE   waiting for the reduce-scatter / all-reduce of the accelerations
+ *   NB_PH_FINISH   nb_step_finish: (all-gather protocol: remote blocks' force,) kick, drift
+ * and the number of steps they cover.  The host runs at most 128 marked steps ahead of the device.  Off by default. */
+enum { NB_PH_LOCAL = 0, NB_PH_AG_WAIT = 1, NB_PH_CROSS = 2, NB_PH_REDUCE = 3, NB_PH_FINISH = 4, NB_COMM_PHASES = 5 };
+int      nb_comm_profile(nb_comm *c, int on);
+int      nb_comm_phase_read(nb_comm *c, int handle, double *phase_ms /* NB_COMM_PHASES */, uint64_t *steps, int reset);
+/* The RCCL id of a one-process-per-GPU launch travelling through a FILE (hosts without MPI or a torch process group):
+ * rank 0 publishes {magic, nonce, id} atomically (temporary file + rename; a stale file of an earlier launch is removed
+ * first), the other ranks wait for a file that carries THEIR launch's nonce — a left-over file of a crashed run, or one
+ * still being replaced, is ignored — at most timeout_ms (NB_EIO after that).  Host-only (no GPU needed). */
+int      nb_comm_id_publish(const char *path, uint64_t nonce, const void *id /* NB_COMM_ID_BYTES */);
+int      nb_comm_id_await(const char *path, uint64_t nonce, void *id_out /* NB_COMM_ID_BYTES */, int timeout_ms);
+/* Test hook: load the nccl* entry points from `path` instead of librccl.so.1 (tests/loopback_rccl.hip: an in-process
+ * transport that lets several ranks share one device, so nb_comm_step can run with 2 and 4 members on a one-GPU box).
+ * Call before anything has loaded the transport; NULL restores the default. */
+int      nb_debug_comm_transport(const char *path);
 
 /* The schedule of ONE step as data: what nb_comm_step issues, in order (host-only view; the CPU tests check call order
  * and element counts with it).  kind: NB_OP_*; handle: index into the process's handle list (-1 for the group ops);

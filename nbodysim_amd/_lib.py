@@ -90,6 +90,7 @@ class nb_params(C.Structure):
         ("first_frame", C.c_uint64),
         ("sym_tile", C.c_int32),
         ("_reserved0", C.c_int32),
+        ("pos_rows", C.c_uint64),
     ]
 
 
@@ -136,6 +137,8 @@ NB_COMM_ID_BYTES = 128
 (NB_OP_BEGIN, NB_OP_MID, NB_OP_FINISH, NB_OP_RECORD, NB_OP_WAIT, NB_OP_ALLGATHER, NB_OP_REDUCE_SCATTER, NB_OP_ALLREDUCE,
  NB_OP_GROUP_START, NB_OP_GROUP_END) = range(10)
 NB_EV_POS, NB_EV_AG, NB_EV_ACC, NB_EV_RED = range(4)
+NB_PH_NAMES = ("local", "ag_wait", "cross", "reduce", "finish")       # NB_PH_* of nb_comm_phase_read
+NB_COMM_PHASES = len(NB_PH_NAMES)
 
 
 #: every symbol include/nbody.h declares: name -> (restype, argtypes)
@@ -170,6 +173,7 @@ PROTOTYPES = {
     "nb_step_finish": (C.c_int, [C.c_void_p]),
     "nb_pos_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "nb_stream": (C.c_void_p, [C.c_void_p]),
+    "nb_pos_rows": (C.c_size_t, [C.c_void_p]),
     "nb_shard_protocol": (C.c_int, [C.c_void_p]),
     "nb_exchange_positions": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nb_exchange_accelerations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -186,6 +190,12 @@ PROTOTYPES = {
     "nb_comm_wait": (C.c_int, [C.c_void_p]),
     "nb_comm_destroy": (None, [C.c_void_p]),
     "nb_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nb_comm_available": (C.c_int, [C.POINTER(C.c_int)]),
+    "nb_comm_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_comm_phase_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "nb_comm_id_publish": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p]),
+    "nb_comm_id_await": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p, C.c_int]),
+    "nb_debug_comm_transport": (C.c_int, [C.c_char_p]),
     "nb_debug_comm_schedule": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),

@@ -23,6 +23,26 @@ def unique_id() -> bytes:
     return buf.raw
 
 
+def available() -> int:
+    """``nb_comm_available``: the RCCL version the library's loop would use; raises ``NBodyError`` if the transport cannot
+    be loaded in this process.  Ranks agree on this before any of them enters ``Comm.rank`` (ncclCommInitRank blocks)."""
+    v = C.c_int()
+    L.check("nb_comm_available", L.load().nb_comm_available(C.byref(v)))
+    return v.value
+
+
+def id_publish(path: str, nonce: int, uid: bytes) -> None:
+    """Rank 0 of a launch without a process group: publish the id through a file, tagged with the launch's nonce."""
+    L.check("nb_comm_id_publish", L.load().nb_comm_id_publish(str(path).encode(), nonce, uid))
+
+
+def id_await(path: str, nonce: int, timeout_ms: int = 60000) -> bytes:
+    """The other ranks: wait for THIS launch's id file (a file with another nonce is ignored); ``NBodyError`` (NB_EIO) on time-out."""
+    buf = C.create_string_buffer(L.NB_COMM_ID_BYTES)
+    L.check("nb_comm_id_await", L.load().nb_comm_id_await(str(path).encode(), nonce, buf, timeout_ms))
+    return buf.raw
+
+
 class Comm:
     """One ``nb_comm``.  ``Comm.all(sims)``: one process drives every rank (one handle per device);
     ``Comm.rank(sim, id, rank, world)``: one process per GPU."""
@@ -59,6 +79,20 @@ class Comm:
 
     def wait(self) -> None:
         L.check("nb_comm_wait", self._lib.nb_comm_wait(self._h))
+
+    def profile(self, on: bool = True) -> None:
+        """Per-phase HIP events inside the library's loop (``nb_comm_profile``); off by default."""
+        L.check("nb_comm_profile", self._lib.nb_comm_profile(self._h, int(on)))
+
+    def phases(self, handle: int = 0, reset: bool = True) -> dict:
+        """``nb_comm_phase_read``: {phase: mean ms per step on the compute stream, ..., "steps": k} for local handle ``handle``."""
+        ms = (C.c_double * L.NB_COMM_PHASES)()
+        steps = C.c_uint64()
+        L.check("nb_comm_phase_read", self._lib.nb_comm_phase_read(self._h, handle, ms, C.byref(steps), int(reset)))
+        k = max(1, int(steps.value))
+        out = {name: ms[i] / k for i, name in enumerate(L.NB_PH_NAMES)}
+        out["steps"] = int(steps.value)
+        return out
 
     def info(self) -> dict:
         p, w, k, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -68,6 +68,7 @@ struct nb_sim {
 
     void *pos[2] = {nullptr, nullptr};
     bool own_pos = true;
+    size_t pos_rows = 0;       // rows each replica holds (>= n: padded to world * ceil(n / world) for a sharded handle)
     int cur = 0;
     void *mass = nullptr;
     float *radius = nullptr;
@@ -673,6 +674,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (p.i_count == 0) { p.i_begin = 0; p.i_count = n; }
     if (p.i_begin + p.i_count > n) { nb_set_error("nb_create: owned block [%llu,+%llu) exceeds n=%zu", (unsigned long long)p.i_begin, (unsigned long long)p.i_count, n); return nullptr; }
     if ((p.pos_buffers[0] == nullptr) != (p.pos_buffers[1] == nullptr)) { nb_set_error("nb_create: give both pos_buffers or none"); return nullptr; }
+    if (p.pos_rows != 0 && (!p.pos_buffers[0] || p.pos_rows < n)) { nb_set_error("nb_create: pos_rows describes caller-owned pos_buffers and must be >= n"); return nullptr; }
     if ((p.acc_buffers[0] == nullptr) != (p.acc_buffers[1] == nullptr)) { nb_set_error("nb_create: give both acc_buffers or none"); return nullptr; }
     if (p.shard_world < 0 || (p.shard_world > 1 && (p.shard_rank < 0 || p.shard_rank >= p.shard_world))) { nb_set_error("nb_create: bad shard_rank/shard_world %d/%d", p.shard_rank, p.shard_world); return nullptr; }
 
@@ -712,10 +714,17 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
     if (s->sym_replicated) s->sym = false;          // the whole-system plan is not built: this rank evaluates its share only
     plan(s);
     const size_t r2 = s->esz;
-    if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; }
+    if (p.pos_buffers[0]) { s->pos[0] = p.pos_buffers[0]; s->pos[1] = p.pos_buffers[1]; s->own_pos = false; s->pos_rows = p.pos_rows ? (size_t)p.pos_rows : n; }
     else {
-        if ((e = hipMalloc(&s->pos[0], n * r2)) != hipSuccess) return fail("hipMalloc pos", e);
-        if ((e = hipMalloc(&s->pos[1], n * r2)) != hipSuccess) return fail("hipMalloc pos", e);
+        // a sharded handle's replicas hold world * ceil(n / world) rows: an all-gather over ragged blocks moves equal counts
+        const size_t w = p.shard_world > 1 ? (size_t)p.shard_world : 1;
+        s->pos_rows = w * ((n + w - 1) / w);
+        if ((e = hipMalloc(&s->pos[0], s->pos_rows * r2)) != hipSuccess) return fail("hipMalloc pos", e);
+        if ((e = hipMalloc(&s->pos[1], s->pos_rows * r2)) != hipSuccess) return fail("hipMalloc pos", e);
+        if (s->pos_rows > n) {          // the padding rows travel with the last block: keep them defined
+            if ((e = hipMemsetAsync((char *)s->pos[0] + n * r2, 0, (s->pos_rows - n) * r2, s->stream)) != hipSuccess) return fail("hipMemset pos", e);
+            if ((e = hipMemsetAsync((char *)s->pos[1] + n * r2, 0, (s->pos_rows - n) * r2, s->stream)) != hipSuccess) return fail("hipMemset pos", e);
+        }
     }
     s->slabs_cap = s->slabs_all > s->slabs_two_phase ? s->slabs_all : s->slabs_two_phase;
     if ((e = hipMalloc(&s->mass, n * s->rsz)) != hipSuccess) return fail("hipMalloc mass", e);
@@ -1527,6 +1536,7 @@ extern "C" size_t nb_owned_begin(const nb_sim *s) { return s ? s->i_begin : 0; }
 extern "C" size_t nb_owned_count(const nb_sim *s) { return s ? s->i_count : 0; }
 extern "C" void *nb_pos_buffer(nb_sim *s, int which) { return s ? s->pos[which == NB_POS_NEXT ? (s->cur ^ 1) : s->cur] : nullptr; }
 extern "C" void *nb_stream(nb_sim *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" size_t nb_pos_rows(const nb_sim *s) { return s ? s->pos_rows : 0; }
 extern "C" int nb_device(const nb_sim *s) { return s ? s->dev : -1; }
 extern "C" int nb_shard_rank(const nb_sim *s, int *world)
 {

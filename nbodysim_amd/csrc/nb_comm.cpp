@@ -20,6 +20,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -46,10 +47,13 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: ends a communicator whose peers may never arrive
+    bool loopback = false;                                // the test-only in-process transport (tests/loopback_rccl.hip): several ranks per device
 };
 
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
+std::string g_transport_path;                             // nb_debug_comm_transport: load THIS library instead of librccl.so.1
 
 template <typename F> bool sym(void *lib, const char *name, F &fn)
 {
@@ -61,8 +65,14 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return NB_OK;
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    void *lib = nullptr;
+    if (!g_transport_path.empty()) {
+        lib = dlopen(g_transport_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return nb_fail(NB_ENODEVICE, "nb_comm: the transport named with nb_debug_comm_transport is not loadable (%s)", dlerror());
+    } else {
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!lib) return nb_fail(NB_ENODEVICE, "nb_comm: RCCL is not loadable (%s); the C-level exchange has no other transport", dlerror());
     Rccl r;
     r.lib = lib;
@@ -73,6 +83,8 @@ int load_rccl()
                     sym(lib, "ncclGroupEnd", r.GroupEnd) && sym(lib, "ncclGetErrorString", r.GetErrorString) &&
                     sym(lib, "ncclGetVersion", r.GetVersion);
     if (!ok) { dlclose(lib); return nb_fail(NB_ENODEVICE, "nb_comm: librccl lacks an expected nccl* symbol"); }
+    (void)sym(lib, "ncclCommAbort", r.CommAbort);
+    r.loopback = dlsym(lib, "nb_loopback_transport") != nullptr;
     g_rccl = r;
     return NB_OK;
 }
@@ -88,12 +100,23 @@ int load_rccl()
         if (r_ != ncclSuccess) return nb_fail(NB_EHIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// per-step timing marks of one member (nb_comm_profile): events on its COMPUTE stream around every compute-stream
+// operation of the schedule, so the phases are what the compute stream sees, waits for the collectives included
+enum : int { PH_LOCAL = 0, PH_AG_WAIT = 1, PH_CROSS = 2, PH_REDUCE = 3, PH_FINISH = 4, PH_COUNT = 5 };
+constexpr int MARKS_PER_STEP = 8;          // start + at most 6 compute-stream operations per step
+constexpr size_t MARK_RING = 128;          // steps in flight with marks: the host blocks on the oldest when the ring is full
+struct StepMarks { hipEvent_t ev[MARKS_PER_STEP]; int phase[MARKS_PER_STEP]; int used = 0; };
+
 struct Member {
     nb_sim *sim = nullptr;
     int dev = 0;
     hipStream_t compute = nullptr, comm = nullptr;
     hipEvent_t ev[EV_COUNT] = {nullptr, nullptr, nullptr, nullptr};
     ncclComm_t nccl = nullptr;
+    std::vector<StepMarks> ring;           // allocated by nb_comm_profile(on)
+    size_t ring_head = 0, ring_count = 0;  // oldest un-harvested step, steps with marks in flight
+    double phase_ms[PH_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t phase_steps = 0;
 };
 
 }  // namespace
@@ -105,6 +128,8 @@ struct nb_comm {
     int reals_per_element = 2, bytes_per_real = 4;
     uint64_t block_reals = 0, full_reals = 0;
     bool ag_pending = false;
+    bool failed = false;                        // a step failed half-way: the peers may wait for collectives this process never joined
+    bool profile = false;
     uint64_t steps = 0;
     std::vector<nb_comm_op> first, steady;      // schedule of the first step (no all-gather in flight) and of all later ones
 };
@@ -119,6 +144,10 @@ int adopt(nb_comm *c, nb_sim *const *sims, int count, int world, const int *rank
     int rpe = 0, bpr = 0;
     if (nb_element_layout(sims[0], &rpe, &bpr)) return nb_last_error_code();
     const size_t n = nb_count(sims[0]);
+    // all-gather protocol: blocks of stride = ceil(n / world) particles, the last one shorter when world does not divide n;
+    // the collective moves `stride` rows per rank whatever the block holds, so the replicas must have world * stride rows
+    // (the library allocates them that way for a sharded handle; caller-owned ones say so in nb_params.pos_rows)
+    const size_t stride = (n + (size_t)world - 1) / (size_t)world;
     for (int k = 0; k < count; ++k) {
         nb_sim *s = sims[k];
         int r2 = 0, b2 = 0;
@@ -132,11 +161,20 @@ int adopt(nb_comm *c, nb_sim *const *sims, int count, int world, const int *rank
         if (proto == NB_SHARD_ALLREDUCE || proto == NB_SHARD_NONE) {
             if (ic != n) return nb_fail(NB_EINVAL, "nb_comm: a replicated / unsharded handle owns all n particles");
             if (proto == NB_SHARD_NONE && world != 1) return nb_fail(NB_EINVAL, "nb_comm: an unsharded handle forms a communicator of one rank only");
-        } else if (n % (size_t)world != 0 || ic != n / (size_t)world || ib != (size_t)ranks[k] * ic) {
+        } else if (proto == NB_SHARD_SYMMETRIC) {
             // equal blocks in rank order: what the in-place ncclAllGather (send = recv + rank * count) and the
             // reduce-scatter (equal receive counts) need
-            return nb_fail(NB_EINVAL, "nb_comm: rank %d must own the block [rank * n/world, +n/world) (n = %zu, world = %d; has [%zu, +%zu))",
-                           ranks[k], n, world, ib, ic);
+            if (n % (size_t)world != 0 || ic != n / (size_t)world || ib != (size_t)ranks[k] * ic)
+                return nb_fail(NB_EINVAL, "nb_comm: rank %d must own the block [rank * n/world, +n/world) (n = %zu, world = %d; has [%zu, +%zu))",
+                               ranks[k], n, world, ib, ic);
+        } else {
+            const size_t want_b = (size_t)ranks[k] * stride;
+            if (want_b >= n || ib != want_b || ic != (n - want_b < stride ? n - want_b : stride))
+                return nb_fail(NB_EINVAL, "nb_comm: rank %d must own the block [rank * ceil(n/world), +...) (n = %zu, world = %d, stride %zu; has [%zu, +%zu))",
+                               ranks[k], n, world, stride, ib, ic);
+            if (nb_pos_rows(s) < (size_t)world * stride)
+                return nb_fail(NB_EINVAL, "nb_comm: world = %d does not divide n = %zu: the position replicas need %zu rows (equal counts per rank), "
+                                          "this handle's hold %zu (caller-owned buffers: say so in nb_params.pos_rows)", world, n, (size_t)world * stride, nb_pos_rows(s));
         }
     }
     c->protocol = proto;
@@ -144,7 +182,7 @@ int adopt(nb_comm *c, nb_sim *const *sims, int count, int world, const int *rank
     c->reals_per_element = rpe;
     c->bytes_per_real = bpr;
     c->full_reals = (uint64_t)n * (uint64_t)rpe;
-    c->block_reals = (uint64_t)nb_owned_count(sims[0]) * (uint64_t)rpe;
+    c->block_reals = (uint64_t)(proto == NB_SHARD_SYMMETRIC ? n / (size_t)world : stride) * (uint64_t)rpe;
     if (proto == NB_SHARD_ALLREDUCE || proto == NB_SHARD_NONE) c->block_reals = c->full_reals / (uint64_t)world;
     c->m.resize((size_t)count);
     for (int k = 0; k < count; ++k) {
@@ -161,27 +199,86 @@ int adopt(nb_comm *c, nb_sim *const *sims, int count, int world, const int *rank
     return NB_OK;
 }
 
+void free_marks(Member &mb)
+{
+    for (StepMarks &sm : mb.ring)
+        for (hipEvent_t e : sm.ev) if (e) (void)hipEventDestroy(e);
+    mb.ring.clear();
+    mb.ring_head = mb.ring_count = 0;
+}
+
 void release(nb_comm *c)
 {
     if (!c) return;
     for (Member &mb : c->m) {
         (void)hipSetDevice(mb.dev);
-        if (mb.comm) (void)hipStreamSynchronize(mb.comm);
-        if (mb.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl);
+        if (c->failed) {
+            // the peers may be waiting inside a collective this process never joined: synchronising the communication
+            // stream or a plain ncclCommDestroy could block for ever — abort the communicator instead
+            if (mb.nccl) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(mb.nccl); else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl); }
+        } else {
+            if (mb.comm) (void)hipStreamSynchronize(mb.comm);
+            if (mb.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl);
+        }
+        free_marks(mb);
         for (hipEvent_t e : mb.ev) if (e) (void)hipEventDestroy(e);
-        if (mb.comm) (void)hipStreamDestroy(mb.comm);
+        if (mb.comm && !c->failed) (void)hipStreamDestroy(mb.comm);
     }
     delete c;
 }
 
-int run_schedule(nb_comm *c, const std::vector<nb_comm_op> &ops, float dt)
+// add the oldest marked step of a member to its phase sums (blocks until that step has run)
+int harvest_one(Member &mb)
+{
+    StepMarks &sm = mb.ring[mb.ring_head];
+    if (sm.used > 1) {
+        HIPC(hipEventSynchronize(sm.ev[sm.used - 1]));
+        for (int k = 1; k < sm.used; ++k) {
+            float ms = 0.f;
+            HIPC(hipEventElapsedTime(&ms, sm.ev[k - 1], sm.ev[k]));
+            if (sm.phase[k] >= 0 && sm.phase[k] < PH_COUNT) mb.phase_ms[sm.phase[k]] += (double)ms;
+        }
+        mb.phase_steps += 1;
+    }
+    sm.used = 0;
+    mb.ring_head = (mb.ring_head + 1) % mb.ring.size();
+    mb.ring_count -= 1;
+    return NB_OK;
+}
+
+int phase_of(const nb_comm_op &o)
+{
+    switch (o.kind) {
+    case OP_BEGIN:  return PH_LOCAL;
+    case OP_MID:    return PH_CROSS;
+    case OP_FINISH: return PH_FINISH;
+    case OP_WAIT:   return o.stream == ST_COMPUTE ? (o.event == EV_AG ? PH_AG_WAIT : o.event == EV_RED ? PH_REDUCE : -1) : -1;
+    default:        return -1;
+    }
+}
+
+int run_schedule_inner(nb_comm *c, const std::vector<nb_comm_op> &ops, float dt, bool &group_open)
 {
     const ncclDataType_t ty = c->bytes_per_real == 8 ? ncclDouble : ncclFloat;
     const size_t esz = (size_t)c->reals_per_element * (size_t)c->bytes_per_real;
     int bound = -1;
+    std::vector<StepMarks *> marks(c->m.size(), nullptr);
+    if (c->profile) {
+        for (size_t k = 0; k < c->m.size(); ++k) {
+            Member &mb = c->m[k];
+            if (mb.ring.empty()) continue;
+            if (bound != mb.dev) { HIPC(hipSetDevice(mb.dev)); bound = mb.dev; }
+            if (mb.ring_count == mb.ring.size()) { const int rc = harvest_one(mb); if (rc) return rc; }
+            StepMarks *sm = &mb.ring[(mb.ring_head + mb.ring_count) % mb.ring.size()];
+            mb.ring_count += 1;
+            sm->used = 1; sm->phase[0] = -1;
+            HIPC(hipEventRecord(sm->ev[0], mb.compute));
+            marks[k] = sm;
+        }
+    }
     for (const nb_comm_op &o : ops) {
-        if (o.kind == OP_GROUP_START) { NCCLC(g_rccl.GroupStart()); continue; }
-        if (o.kind == OP_GROUP_END) { NCCLC(g_rccl.GroupEnd()); continue; }
+        if (o.kind == OP_GROUP_START) { NCCLC(g_rccl.GroupStart()); group_open = true; continue; }
+        if (o.kind == OP_GROUP_END) { group_open = false; NCCLC(g_rccl.GroupEnd()); continue; }
         Member &mb = c->m[(size_t)o.handle];
         if (bound != mb.dev) { HIPC(hipSetDevice(mb.dev)); bound = mb.dev; }
         hipStream_t st = o.stream == ST_COMM ? mb.comm : mb.compute;
@@ -210,11 +307,52 @@ int run_schedule(nb_comm *c, const std::vector<nb_comm_op> &ops, float dt)
             return nb_fail(NB_ESTATE, "nb_comm: unknown schedule op %d", o.kind);
         }
         if (rc) return rc;
+        StepMarks *sm = marks[(size_t)o.handle];
+        const int ph = phase_of(o);
+        if (sm && ph >= 0 && sm->used < MARKS_PER_STEP) {
+            sm->phase[sm->used] = ph;
+            HIPC(hipEventRecord(sm->ev[sm->used], mb.compute));
+            sm->used += 1;
+        }
     }
     return NB_OK;
 }
 
+// One step.  If an operation fails half-way the communicator is marked FAILED (an open ncclGroup is closed first): the
+// peers may already wait inside collectives this process will never issue, so nothing may block on the communication
+// stream any more — nb_comm_destroy then aborts the RCCL communicator instead of synchronising (release()).
+int run_schedule(nb_comm *c, const std::vector<nb_comm_op> &ops, float dt)
+{
+    bool group_open = false;
+    const int rc = run_schedule_inner(c, ops, dt, group_open);
+    if (rc) {
+        if (group_open) (void)g_rccl.GroupEnd();
+        c->failed = true;
+    }
+    return rc;
+}
+
 }  // namespace
+
+// Name the library that provides the nccl* entry points (instead of librccl.so.1).  Test hook: tests/loopback_rccl.hip is an
+// in-process transport over device buffers that lets several ranks share ONE device, so the executor above can be run
+// with 2 and 4 members on a one-GPU box.  Must be called before the first nb_comm_* call that loads the transport.
+extern "C" int nb_debug_comm_transport(const char *path)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return nb_fail(NB_ESTATE, "nb_debug_comm_transport: a transport is already loaded in this process");
+    g_transport_path = path ? path : "";
+    return NB_OK;
+}
+
+// NB_OK iff the transport can be loaded in this process (and its version); every rank of a one-process-per-GPU job
+// checks this and the ranks AGREE on it before any of them enters the blocking ncclCommInitRank.
+extern "C" int nb_comm_available(int *rccl_version)
+{
+    if (load_rccl()) return nb_last_error_code();
+    if (rccl_version) { int v = 0; (void)g_rccl.GetVersion(&v); *rccl_version = v; }
+    return NB_OK;
+}
 
 extern "C" int nb_comm_unique_id(void *id_out)
 {
@@ -259,7 +397,7 @@ extern "C" nb_comm *nb_comm_create_all(nb_sim *const *sims, int count)
     if (adopt(c, sims, count, count, ranks.data())) { release(c); return nullptr; }
     for (int k = 0; k < count; ++k) {
         devs[(size_t)k] = c->m[(size_t)k].dev;
-        for (int j = 0; j < k; ++j)
+        for (int j = 0; j < k && !g_rccl.loopback; ++j)
             if (devs[(size_t)j] == devs[(size_t)k]) {
                 nb_fail(NB_EINVAL, "nb_comm_create_all: handles %d and %d share device %d — RCCL takes one rank per device "
                                    "(several handles on one device exchange with nb_exchange_*)", j, k, devs[(size_t)k]);
@@ -281,6 +419,7 @@ extern "C" int nb_comm_step(nb_comm *c, float dt, int nsteps)
 {
     if (!c) return nb_fail(NB_EINVAL, "nb_comm_step: NULL communicator");
     if (nsteps < 0) return nb_fail(NB_EINVAL, "nb_comm_step: nsteps < 0");
+    if (c->failed) return nb_fail(NB_ESTATE, "nb_comm_step: an earlier step failed half-way; destroy the communicator and the handles");
     for (int k = 0; k < nsteps; ++k) {
         const int rc = run_schedule(c, c->ag_pending ? c->steady : c->first, dt);
         if (rc) return rc;
@@ -295,6 +434,7 @@ extern "C" int nb_comm_step(nb_comm *c, float dt, int nsteps)
 extern "C" int nb_comm_flush(nb_comm *c)
 {
     if (!c) return nb_fail(NB_EINVAL, "nb_comm_flush: NULL communicator");
+    if (c->failed) return nb_fail(NB_ESTATE, "nb_comm_flush: the communicator has failed");
     if (!c->ag_pending) return NB_OK;
     for (Member &mb : c->m) {
         HIPC(hipSetDevice(mb.dev));
@@ -319,7 +459,7 @@ extern "C" int nb_comm_wait(nb_comm *c)
 
 extern "C" void nb_comm_destroy(nb_comm *c)
 {
-    if (c) (void)nb_comm_wait(c);
+    if (c && !c->failed) (void)nb_comm_wait(c);
     release(c);
 }
 
@@ -330,6 +470,38 @@ extern "C" int nb_comm_info(const nb_comm *c, int *protocol, int *world, int *lo
     if (world) *world = c->world;
     if (local_handles) *local_handles = (int)c->m.size();
     if (rccl_version) { int v = 0; if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v); *rccl_version = v; }
+    return NB_OK;
+}
+
+// Per-phase timing inside the library's loop: HIP events on each handle's compute stream around every compute-stream
+// operation of a step (MARK_RING steps deep; when the ring is full the host waits for the oldest marked step, so with
+// profiling on it runs at most that far ahead).  Off by default: the loop then records no timing event at all.
+extern "C" int nb_comm_profile(nb_comm *c, int on)
+{
+    if (!c) return nb_fail(NB_EINVAL, "nb_comm_profile: NULL communicator");
+    for (Member &mb : c->m) {
+        HIPC(hipSetDevice(mb.dev));
+        while (mb.ring_count) { const int rc = harvest_one(mb); if (rc) return rc; }
+        if (on && mb.ring.empty()) {
+            mb.ring.resize(MARK_RING);
+            for (StepMarks &sm : mb.ring)
+                for (hipEvent_t &e : sm.ev) { e = nullptr; HIPC(hipEventCreate(&e)); }
+        }
+        if (!on) free_marks(mb);
+    }
+    c->profile = on != 0;
+    return NB_OK;
+}
+
+extern "C" int nb_comm_phase_read(nb_comm *c, int handle, double *phase_ms, uint64_t *steps, int reset)
+{
+    if (!c || handle < 0 || (size_t)handle >= c->m.size()) return nb_fail(NB_EINVAL, "nb_comm_phase_read: bad arguments");
+    Member &mb = c->m[(size_t)handle];
+    HIPC(hipSetDevice(mb.dev));
+    while (mb.ring_count) { const int rc = harvest_one(mb); if (rc) return rc; }
+    if (phase_ms) for (int k = 0; k < PH_COUNT; ++k) phase_ms[k] = mb.phase_ms[k];
+    if (steps) *steps = mb.phase_steps;
+    if (reset) { for (double &v : mb.phase_ms) v = 0.0; mb.phase_steps = 0; }
     return NB_OK;
 }
 

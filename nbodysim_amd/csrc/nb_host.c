@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 /* ---- errors: text and NB_E* code of the last failure on the calling thread ---- */
 static _Thread_local char g_err[512] = "";
@@ -409,4 +411,58 @@ int nb_read_bodies(const char *path, nb_body *out, size_t n)
         rc = nb_fail(NB_EFORMAT, "%s: truncated body records", path);
     fclose(f);
     return rc;
+}
+
+/* ---- the RCCL id of a one-process-per-GPU launch through a file (include/nbody.h: nb_comm_id_publish / _await) ----
+ * File = {"NBCOMMID", u64 nonce, NB_COMM_ID_BYTES id}.  The nonce names the LAUNCH (every rank is started with the
+ * same one): a file left behind by a run that crashed before rank 0 could unlink it, or by a rank 0 that has not yet
+ * replaced it, carries another nonce and is ignored by the waiting ranks instead of feeding ncclCommInitRank an id
+ * nobody else holds (which blocks for ever inside RCCL). */
+typedef struct nb_idfile { char magic[8]; uint64_t nonce; unsigned char id[NB_COMM_ID_BYTES]; } nb_idfile;
+
+int nb_comm_id_publish(const char *path, uint64_t nonce, const void *id)
+{
+    if (!path || !id) return nb_fail(NB_EINVAL, "nb_comm_id_publish: NULL argument");
+    char tmp[4096];
+    if (snprintf(tmp, sizeof tmp, "%s.tmp.%ld", path, (long)getpid()) >= (int)sizeof tmp) return nb_fail(NB_EINVAL, "nb_comm_id_publish: path too long");
+    (void)unlink(path);                       /* a stale file of an earlier launch must not be read while this one is being written */
+    nb_idfile rec;
+    memcpy(rec.magic, "NBCOMMID", 8);
+    rec.nonce = nonce;
+    memcpy(rec.id, id, NB_COMM_ID_BYTES);
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return nb_fail(NB_EIO, "nb_comm_id_publish: cannot create %s: %s", tmp, strerror(errno));
+    const int ok = fwrite(&rec, sizeof rec, 1, f) == 1;
+    if (fclose(f) != 0 || !ok || rename(tmp, path) != 0) {
+        (void)unlink(tmp);
+        return nb_fail(NB_EIO, "nb_comm_id_publish: cannot publish %s: %s", path, strerror(errno));
+    }
+    return NB_OK;
+}
+
+int nb_comm_id_await(const char *path, uint64_t nonce, void *id_out, int timeout_ms)
+{
+    if (!path || !id_out || timeout_ms < 0) return nb_fail(NB_EINVAL, "nb_comm_id_await: bad argument");
+    struct timespec t0, now;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int stale = 0;
+    for (;;) {
+        FILE *f = fopen(path, "rb");
+        if (f) {
+            nb_idfile rec;
+            const int whole = fread(&rec, sizeof rec, 1, f) == 1;
+            fclose(f);
+            if (whole && memcmp(rec.magic, "NBCOMMID", 8) == 0) {
+                if (rec.nonce == nonce) { memcpy(id_out, rec.id, NB_COMM_ID_BYTES); return NB_OK; }
+                stale = 1;                    /* another launch's file: keep waiting for ours */
+            }
+        }
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const double ms = (double)(now.tv_sec - t0.tv_sec) * 1e3 + (double)(now.tv_nsec - t0.tv_nsec) * 1e-6;
+        if (ms >= (double)timeout_ms)
+            return nb_fail(NB_EIO, "nb_comm_id_await: no RCCL id of this launch (nonce %llu) in %s after %d ms%s", (unsigned long long)nonce, path,
+                           timeout_ms, stale ? " (the file there belongs to another launch)" : "");
+        const struct timespec nap = {0, 20000000L};
+        nanosleep(&nap, NULL);
+    }
 }

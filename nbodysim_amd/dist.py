@@ -47,6 +47,9 @@ force/integrate work is the C ABI's.
 """
 from __future__ import annotations
 
+import os
+import sys
+import threading
 import time
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional, Sequence, Tuple
@@ -57,6 +60,48 @@ from . import _lib as L
 
 PROTOCOLS = ("auto", "symmetric", "allgather", "allreduce", "tune")
 DRIVERS = ("torch", "c", "tune")
+EXIT_DEADLINE = 3      # exit status of a rank whose Watchdog expired
+
+
+class Watchdog:
+    """A wall-clock deadline around a stretch of code that can block for ever inside a collective (a peer that died, a
+    mismatched collective count, a communicator that never forms).  On expiry it prints what was running and the
+    caller's report to stderr and ends the PROCESS with status ``EXIT_DEADLINE`` (``os._exit``: no re-exec — the process has
+    touched the GPU — and no unwinding through the blocked call); the launcher then sees a non-zero exit naming the
+    culprit instead of a silent hang.  The blocked calls (torch.distributed, HIP synchronisation, ctypes) all release the
+    GIL, so the timer thread runs.  ``seconds`` <= 0 disables it."""
+
+    def __init__(self, seconds: float, what: str, report: Optional[Callable[[], object]] = None, rank: Optional[int] = None,
+                 exit_fn: Callable[[int], None] = os._exit):
+        self.seconds, self.what, self.report, self.rank, self.exit_fn = float(seconds), what, report, rank, exit_fn
+        self._timer: Optional[threading.Timer] = None
+
+    def _expire(self) -> None:
+        try:
+            who = f"rank {self.rank}: " if self.rank is not None else ""
+            msg = f"[nbodysim_amd watchdog] {who}deadline of {self.seconds:.0f} s expired while {self.what}"
+            if self.report is not None:
+                try:
+                    msg += f" | so far: {self.report()}"
+                except Exception as e:      # the report must never keep the process alive
+                    msg += f" | (report failed: {e})"
+            sys.stderr.write(msg + "\n")
+            sys.stderr.flush()
+        finally:
+            self.exit_fn(EXIT_DEADLINE)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self._expire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+        return False
 
 
 @dataclass(frozen=True)
@@ -175,6 +220,24 @@ def agree_on_fastest(local_seconds: Dict[str, float], group=None,
     return best, job
 
 
+def time_candidates(names: Sequence[str], run_one: Callable[[str, Dict[str, float]], float], group=None, deadline_s: float = 120.0,
+                    rank: int = 0, prefer: Sequence[str] = (), log: Optional[Callable[[str], None]] = None):
+    """The start-up timing as a pure driver (testable over gloo on the CPU): ``run_one(name, local_so_far)`` runs one
+    candidate on this rank and returns its seconds per step (``inf`` = unavailable); candidates run in the order given —
+    simplest first, so that the plainest protocol has a number before anything exotic is tried — each under its own
+    ``Watchdog``: a rank stuck inside a candidate ends the job with a non-zero exit that NAMES the candidate and lists the
+    timings gathered so far, on every rank that waits for it.  Returns (winner, {name: job seconds}) from
+    ``agree_on_fastest``."""
+    local: Dict[str, float] = {}
+    for name in names:
+        with Watchdog(deadline_s, f"timing the start-up candidate '{name}'", report=lambda: dict(local), rank=rank):
+            local[name] = float(run_one(name, local))
+        if log is not None:
+            v = local[name]
+            log(f"[tune] rank {rank}: {name}: " + (f"{v * 1e3:.3f} ms/step" if np.isfinite(v) else "unavailable"))
+    return agree_on_fastest(local, group, prefer=tuple(prefer) if prefer else tuple(names))
+
+
 _AGREE_FIELDS = ("created", "protocol", "chunks_per_item", "cross_units_total", "local_units", "tiles", "cus", "late")
 
 
@@ -189,6 +252,8 @@ class DistributedSimulation:
                             agree by all-reduce): the symmetric split as the library would size it, the same with the
                             held-back "late" local items switched the other way (they hide the reduce-scatter; on by
                             default from 8 ranks), and the all-gather protocol
+    deadline_s seconds a start-up candidate (and the formation of the C-level communicator) may take before the rank prints
+               what it was doing and exits with status 3 (``Watchdog``); <= 0 disables
     driver     "torch"      this module issues the collectives through torch.distributed (RCCL via ProcessGroupNCCL)
                             between the library's split-step calls, one Python iteration per step
                "c"          the library's own loop (``nb_comm_step``, nbodysim_amd/csrc/nb_comm.cpp): RCCL collectives on
@@ -201,7 +266,8 @@ class DistributedSimulation:
 
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
                  order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
-                 protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, driver: str = "torch", **sim_kwargs):
+                 protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, driver: str = "torch",
+                 deadline_s: float = 120.0, **sim_kwargs):
         import torch
         import torch.distributed as dist
 
@@ -235,6 +301,7 @@ class DistributedSimulation:
         self._host_steps = 0
         self.comm = None
         self.driver = "torch"
+        self.deadline_s = float(deadline_s)     # per start-up candidate and for forming the C-level communicator; <= 0: none
 
         extra: dict = {}
         if protocol == "tune" and world > 1:
@@ -250,9 +317,6 @@ class DistributedSimulation:
         """Allocate the replicas, create the handle, and verify that every rank got the same pair split.  A rank
         whose nb_create fails still reaches the collective, so the job fails on every rank instead of hanging."""
         from .simulation import Simulation
-
-        if driver == "c" and self.plan.ragged:
-            raise RuntimeError("driver='c' needs equal blocks (world must divide n): nb_comm's in-place all-gather and reduce-scatter")
 
         torch, world, rank = self.torch, self.plan.world, self.plan.rank
         err: Optional[BaseException] = None
@@ -278,7 +342,7 @@ class DistributedSimulation:
             self.sim = Simulation(
                 bodies, device=self._device_index,
                 i_begin=0 if replicated else self.plan.i_begin, i_count=self.plan.n if replicated else self.plan.i_count,
-                stream=self.stream.cuda_stream, pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()),
+                stream=self.stream.cuda_stream, pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()), pos_rows=self.plan.padded_n,
                 shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, shard_allreduce=replicated, **kw,
             )
         except (L.NBodyError, RuntimeError, MemoryError) as e:   # keep going to the collective below
@@ -323,12 +387,24 @@ class DistributedSimulation:
     def _create_comm(self) -> None:
         """The library's own RCCL communicator for this run (``nb_comm_create_rank``): rank 0's id goes to the other
         ranks through the torch process group; every rank reports success or failure before anyone proceeds."""
-        from .comm import Comm, unique_id
+        from .comm import Comm, available, unique_id
 
         torch, dist, world, rank = self.torch, self.dist, self.plan.world, self.plan.rank
         dev = _comm_device(self.group)
-        uid = torch.zeros(L.NB_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        # 1. can EVERY rank load the transport?  Agreed before anyone enters ncclCommInitRank, which blocks until all
+        #    ranks have arrived: a rank whose dlopen fails would otherwise leave the others waiting inside RCCL for ever.
         err: Optional[BaseException] = None
+        try:
+            available()
+        except L.NBodyError as e:
+            err = e
+        ok, lo, _ = ranks_agree([0 if err is not None else 1], self.group)
+        if not ok or lo[0] == 0:
+            self.sim.close()
+            self.sim = None
+            raise RuntimeError(f"rank {rank}: the C-level RCCL communicator could not be formed on every rank (RCCL not loadable on some rank)"
+                               + (f"; this rank: {err}" if err is not None else "")) from err
+        uid = torch.zeros(L.NB_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         if rank == 0:
             try:
                 uid = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).to(dev)
@@ -338,7 +414,8 @@ class DistributedSimulation:
         raw = bytes(uid.cpu().numpy().tobytes())
         if err is None and any(raw):
             try:
-                self.comm = Comm.rank(self.sim, raw, rank, world)
+                with Watchdog(self.deadline_s, "forming the C-level RCCL communicator (ncclCommInitRank blocks until every rank arrives)", rank=rank):
+                    self.comm = Comm.rank(self.sim, raw, rank, world)
             except L.NBodyError as e:
                 err = e
         elif err is None:
@@ -359,31 +436,32 @@ class DistributedSimulation:
         the caller's bodies at frame 0.  Returns (protocol, extra Simulation keyword arguments, driver).
         A replicated (all-reduce) candidate must also pass the divergence check on this transport — every rank ends
         the trial with bit-identical positions — or it is disqualified."""
-        local: Dict[str, float] = {}
         late_default_on = self.plan.world >= 8 and float(self._args.get("sym_late_us", 0.0)) == 0.0
         flipped = ("symmetric-late", {"sym_late_us": -1.0}) if late_default_on else ("symmetric+late", {"sym_late_us": 40.0})
-        base = {"symmetric": ("symmetric", {}), flipped[0]: ("symmetric", flipped[1]), "allreduce": ("allreduce", {}),
-                "allgather": ("allgather", {})}
+        # simplest first: north_star's plain all-gather, then one collective per step (all-reduce), then the symmetric
+        # split with its two collectives, then the same with the late items flipped
+        base = {"allgather": ("allgather", {}), "allreduce": ("allreduce", {}), "symmetric": ("symmetric", {}),
+                flipped[0]: ("symmetric", flipped[1])}
         if float(self._args.get("sym_late_us", 0.0)) != 0.0:      # the caller fixed the late share: nothing to flip
             del base[flipped[0]]
         nccl = self.dist.get_backend(self.group) == "nccl"
-        drivers = [d for d in (("torch", "c") if driver == "tune" else (driver,)) if d == "torch" or (nccl and not self.plan.ragged)]
+        drivers = [d for d in (("torch", "c") if driver == "tune" else (driver,)) if d == "torch" or nccl]
         cands = {}
-        for d in drivers:
+        for d in drivers:                                         # every torch-driven candidate before any C-loop one
             for name, (cand, extra) in base.items():
                 cands[name if d == "torch" else "c:" + name] = (cand, extra, d)
-        for name, (cand, extra, d) in cands.items():
+
+        def run_one(name: str, local: Dict[str, float]) -> float:
+            cand, extra, d = cands[name]
             pre = "c:" if d == "c" else ""
-            if local.get(pre + "symmetric") == float("inf") and cand in ("symmetric", "allreduce"):
-                local[name] = float("inf")
-                continue
+            if local.get(pre + "symmetric") == float("inf") and cand == "symmetric" and name != pre + "symmetric":
+                return float("inf")                               # not eligible once, not eligible with the late items flipped
             try:
                 self._create(bodies, cand, extra, d)
             except RuntimeError as e:
                 if "not eligible" not in str(e) and "communicator could not be formed" not in str(e):
                     raise
-                local[name] = float("inf")
-                continue
+                return float("inf")
             self.advance(2, dt)
             self.wait()
             self.dist.barrier(group=self.group)
@@ -391,13 +469,18 @@ class DistributedSimulation:
             self.advance(steps, dt)
             self.wait()
             self.dist.barrier(group=self.group)
-            local[name] = (time.perf_counter() - t0) / steps
+            per_step = (time.perf_counter() - t0) / steps
             if self.replicated and not self.replicas_identical():
-                local[name] = float("inf")
+                per_step = float("inf")
             self.close()
+            return per_step
+
+        log = (lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush())) if self.plan.rank == 0 else None
         prefer = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather")
-        best, job = agree_on_fastest(local, self.group, prefer=tuple("c:" + k for k in prefer) + prefer)
-        self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best}
+        best, job = time_candidates(list(cands), run_one, self.group, self.deadline_s, self.plan.rank,
+                                    prefer=prefer + tuple("c:" + k for k in prefer), log=log)
+        self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best,
+                       "order": list(cands), "deadline_s_per_candidate": self.deadline_s}
         return cands[best]
 
     def replicas_identical(self) -> bool:
@@ -503,6 +586,8 @@ class DistributedSimulation:
         self._phase_on = bool(on)
         self._phase_events = []
         self._host_enqueue_s, self._host_steps = 0.0, 0
+        if self.comm is not None:
+            self.comm.profile(on)
 
     def phase_report(self) -> dict:
         """Mean milliseconds per step of each phase AS SEEN BY THE COMPUTE STREAM (waiting included), plus the host's
@@ -510,9 +595,21 @@ class DistributedSimulation:
         all-gather: local | ag_wait | remote_finish.  When the local items run on the side stream
         (``local_on_side_stream``) their time shows up inside `cross`, which joins them."""
         self.wait()
-        if self.comm is not None:                 # the C loop records no per-phase events: only its host cost is known here
-            return {"host_enqueue": self._host_enqueue_s / max(1, self._host_steps) * 1e3, "steps": self._host_steps,
-                    "driver": "c (nb_comm_step): phases are not timed inside the library's loop"}
+        if self.comm is not None:                 # the library's loop times its own phases (nb_comm_profile / nb_comm_phase_read)
+            ph = self.comm.phases(0, reset=True) if self._phase_on else {"steps": 0}
+            if self.symmetric:
+                out = {"local": ph.get("local", 0.0), "ag_wait": ph.get("ag_wait", 0.0), "cross": ph.get("cross", 0.0),
+                       "reduce_scatter": ph.get("reduce", 0.0), "finish": ph.get("finish", 0.0)}
+            elif self.replicated:
+                out = {"force": ph.get("local", 0.0), "all_reduce": ph.get("reduce", 0.0), "finish": ph.get("finish", 0.0)}
+            else:
+                out = {"local": ph.get("local", 0.0), "ag_wait": ph.get("ag_wait", 0.0), "remote_finish": ph.get("finish", 0.0)}
+            out["stream_total"] = sum(out.values())
+            out["host_enqueue"] = self._host_enqueue_s / max(1, self._host_steps) * 1e3
+            out["steps"] = self._host_steps
+            out["phase_steps"] = ph["steps"]          # steps the phase events cover (0 unless profile_phases(True))
+            out["driver"] = "c (nb_comm_step): HIP events inside the library's loop"
+            return out
         names = (("local", "ag_wait", "cross", "reduce_scatter", "finish") if self.symmetric else
                  ("force", "all_reduce", "finish") if self.replicated else ("local", "ag_wait", "remote_finish"))
         tot = {k: 0.0 for k in names}

@@ -18,16 +18,22 @@
  *                            communication stream per handle, event-ordered, no host sync in the loop); needs one device
  *                            per shard.  -shards 1 -rccl runs the sharded protocol with ONE rank (NB_FLAG_SHARD_SINGLE):
  *                            the whole split-step + RCCL path on a one-GPU box
- *              [-rank R -world P -idfile F [-device D]]  ONE PROCESS PER GPU, plain C: this process is rank R of P; rank 0
- *                            creates the RCCL id (nb_comm_unique_id) and publishes it through file F (written to F.tmp, then
- *                            renamed), the others wait for F; every rank builds the same initial bodies, owns block R, and
- *                            the whole step loop is nb_comm_step.  Launch: for r in 0..P-1: nbody_main -rank $r -world P -idfile F &
+ *              [-rank R -world P -idfile F [-nonce X] [-deadline S] [-device D]]  ONE PROCESS PER GPU, plain C: this process is
+ *                            rank R of P; rank 0 creates the RCCL id (nb_comm_unique_id) and publishes it through file F together
+ *                            with the launch's nonce X (nb_comm_id_publish: a stale F is removed first, the new one appears
+ *                            atomically); the others wait for a file carrying THEIR nonce (nb_comm_id_await), so a file left by
+ *                            a crashed run is never mistaken for this launch's.  Give every rank of one launch the same X (default
+ *                            0; e.g. $(date +%s%N)).  Forming the communicator is bounded by -deadline seconds (default 120): a
+ *                            rank whose peers never arrive exits with status 3 instead of waiting inside RCCL for ever.  Every
+ *                            rank builds the same initial bodies, owns block R, and the whole step loop is nb_comm_step.
+ *                            Launch: X=$(date +%s%N); for r in 0..P-1: nbody_main -rank $r -world P -idfile F -nonce $X &
  *                            (-world 1 runs the sharded protocol with one rank: the single-GPU rehearsal)
  * -load FILE restarts from a dump: eps, dt, precision, rsqrt mode, sum order, integrator and extras come from its
  * header unless the command line gives them (options are applied in order, so put -load first to override).
  */
 #include "nbody.h"
 
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,6 +47,17 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* deadline on communicator formation: ncclCommInitRank blocks until every rank has arrived, with no timeout of its own */
+static const char *g_deadline_what = "";
+static void on_deadline(int sig)
+{
+    (void)sig;
+    static const char msg[] = "nbody_main: deadline expired while ";
+    if (write(2, msg, sizeof msg - 1) < 0) _exit(3);
+    if (write(2, g_deadline_what, strlen(g_deadline_what)) < 0 || write(2, "\n", 1) < 0) _exit(3);
+    _exit(3);      /* never a re-exec: the process may have initialised the GPU */
+}
+
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
 #define CHECK(call) do { int rc_ = (call); if (rc_ != NB_OK) DIE("%s -> %d: %s", #call, rc_, nb_last_error()); } while (0)
 
@@ -49,7 +66,8 @@ int main(int argc, char **argv)
     size_t n = 65536;
     uint64_t frame0 = 0;
     int steps = 20, sync_every = 0, shards = 1, reference_ics = 0, n_given = 0, rccl = 0, shards_given = 0;
-    int rank = -1, world = 0, device = -1;
+    int rank = -1, world = 0, device = -1, deadline_s = 120;
+    unsigned long long nonce = 0;
     const char *idfile = NULL;
     unsigned seed = 42;
     const char *dump = NULL, *load = NULL;
@@ -91,6 +109,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-world") && i + 1 < argc) world = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-idfile") && i + 1 < argc) idfile = argv[++i];
+        else if (!strcmp(argv[i], "-nonce") && i + 1 < argc) nonce = strtoull(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "-deadline") && i + 1 < argc) deadline_s = atoi(argv[++i]);
         else DIE("unknown argument %s", argv[i]);
     }
 
@@ -113,31 +133,33 @@ int main(int argc, char **argv)
 
     if (world > 0) {
         /* one process per GPU: this process is rank `rank` of `world`; the communicator is formed from an id file */
-        if (rank < 0 || rank >= world || !idfile || n % (size_t)world) DIE("-rank R -world P -idfile F: 0 <= R < P, P must divide n");
+        /* blocks of ceil(n / P) particles, the last one shorter when P does not divide n (all-gather protocol: equal counts over
+         * padded replicas, which the library allocates) */
+        const size_t blk = (n + (size_t)(world > 0 ? world : 1) - 1) / (size_t)(world > 0 ? world : 1);
+        if (rank < 0 || rank >= world || !idfile || (size_t)(world - 1) * blk >= n) DIE("-rank R -world P -idfile F: 0 <= R < P, every rank must own at least one particle");
         const int ndev = nb_device_count();
-        const size_t blk = n / (size_t)world;
         nb_params q = p;
         q.device = device >= 0 ? device : (ndev > 0 ? rank % ndev : 0);
         q.shard_rank = rank; q.shard_world = world;
-        q.i_begin = (uint64_t)rank * blk; q.i_count = blk;
+        q.i_begin = (uint64_t)rank * blk; q.i_count = n - (size_t)rank * blk < blk ? n - (size_t)rank * blk : blk;
         if (p.flags & NB_FLAG_SHARD_ALLREDUCE) { q.i_begin = 0; q.i_count = n; }
         if (world == 1) q.flags |= NB_FLAG_SHARD_SINGLE;
         nb_sim *h = nb_create(bodies, n, &q);
         if (!h) DIE("nb_create(rank %d): %s", rank, nb_last_error());
-        char id[NB_COMM_ID_BYTES], tmpname[4096];
+        char id[NB_COMM_ID_BYTES];
+        if (deadline_s < 1) deadline_s = 1;
+        CHECK(nb_comm_available(NULL));                    /* a rank without RCCL stops HERE, before anyone waits for it inside RCCL */
         if (rank == 0) {
             CHECK(nb_comm_unique_id(id));
-            snprintf(tmpname, sizeof tmpname, "%s.tmp", idfile);
-            FILE *f = fopen(tmpname, "wb");
-            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmpname, idfile) != 0) DIE("cannot publish the RCCL id in %s", idfile);
+            CHECK(nb_comm_id_publish(idfile, nonce, id));
         } else {
-            FILE *f = NULL;
-            const struct timespec tenth = {0, 100000000L};
-            for (int tries = 0; tries < 600 && !(f = fopen(idfile, "rb")); ++tries) nanosleep(&tenth, NULL);   /* up to 60 s for rank 0 */
-            if (!f || fread(id, 1, sizeof id, f) != sizeof id) DIE("rank %d: no RCCL id in %s after 60 s", rank, idfile);
-            fclose(f);
+            CHECK(nb_comm_id_await(idfile, nonce, id, deadline_s * 1000));
         }
+        g_deadline_what = "forming the RCCL communicator (ncclCommInitRank): a peer never arrived";
+        signal(SIGALRM, on_deadline);
+        alarm((unsigned)deadline_s);
         nb_comm *comm = nb_comm_create_rank(h, id, rank, world);
+        alarm(0);
         if (!comm) DIE("nb_comm_create_rank(rank %d of %d): %s", rank, world, nb_last_error());
         int proto = 0, ver = 0;
         CHECK(nb_comm_info(comm, &proto, NULL, NULL, &ver));
@@ -158,7 +180,7 @@ int main(int argc, char **argv)
         if (dump) {                                        /* every rank dumps its own block (whole system for the replicated protocol) */
             char name[4096];
             snprintf(name, sizeof name, "%s.rank%d", dump, rank);
-            const size_t first = proto == NB_SHARD_ALLREDUCE ? 0 : (size_t)rank * blk, cnt = proto == NB_SHARD_ALLREDUCE ? n : blk;
+            const size_t first = proto == NB_SHARD_ALLREDUCE ? 0 : (size_t)rank * blk, cnt = proto == NB_SHARD_ALLREDUCE ? n : (size_t)q.i_count;
             CHECK(nb_write_bodies(name, bodies + first, cnt, nb_frame(h), &p));
             printf("dumped %zu bodies to %s\n", cnt, name);
         }
@@ -170,14 +192,15 @@ int main(int argc, char **argv)
     }
     if (shards > 1 || (shards_given && rccl)) {
         /* one process, `shards` handles: each integrates a contiguous block */
-        if (shards < 1 || shards > 64 || n % (size_t)shards) DIE("-shards must divide n (and be 1..64)");
+        if (shards < 1 || shards > 64) DIE("-shards 1..64");
         nb_sim *h[64];
         const int ndev = nb_device_count();
-        const size_t blk = n / (size_t)shards;
+        const size_t blk = (n + (size_t)shards - 1) / (size_t)shards;      /* the last block is shorter when shards does not divide n */
+        if ((size_t)(shards - 1) * blk >= n) DIE("-shards %d: every shard must own at least one of the %zu particles", shards, n);
         if (shards == 1) p.flags |= NB_FLAG_SHARD_SINGLE;      /* one rank: every pair is local, the collectives are one-rank copies */
         for (int r = 0; r < shards; ++r) {
             nb_params q = p;
-            q.i_begin = (uint64_t)r * blk; q.i_count = blk; q.device = ndev > 0 ? r % ndev : 0;
+            q.i_begin = (uint64_t)r * blk; q.i_count = n - (size_t)r * blk < blk ? n - (size_t)r * blk : blk; q.device = ndev > 0 ? r % ndev : 0;
             if (p.flags & NB_FLAG_SHARD_ALLREDUCE) { q.i_begin = 0; q.i_count = n; }     /* replicated: every handle integrates all n */
             q.shard_rank = r; q.shard_world = shards;   /* lets the library pick the symmetric protocol where it applies */
             h[r] = nb_create(bodies, n, &q);

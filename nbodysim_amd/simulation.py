@@ -65,6 +65,7 @@ class Simulation:
         mass_scaling: bool = False,
         sym_chunk_pairs: int = 0,
         sym_tile: int = 0,
+        pos_rows: int = 0,
     ):
         """The last eight arguments are ``nb_params.flags`` and the launch-geometry tuning fields
         (0 / True = the library's automatic choice); the library reads no environment variables."""
@@ -100,6 +101,7 @@ class Simulation:
         p.first_frame = first_frame
         p.sym_chunk_pairs = sym_chunk_pairs
         p.sym_tile = sym_tile
+        p.pos_rows = pos_rows
         p.shard_rank, p.shard_world = shard_rank, shard_world
         if acc_buffers is not None:
             p.acc_buffers[0], p.acc_buffers[1] = acc_buffers

@@ -161,3 +161,56 @@ def test_c_driver_one_process_per_gpu_form(tmp_path):
     assert fb == 6 and np.max(np.abs(ba["pos"] - bb["pos"])) <= 2e-6 * np.max(np.abs(bb["pos"]))
     bad = subprocess.run([str(exe), *common, "-rank", "1", "-world", "1", "-idfile", str(idf)], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "0 <= R < P" in bad.stderr
+    # a rank whose rank 0 never publishes THIS launch's id gives up at its deadline instead of waiting for ever; a stale
+    # file of another launch (other nonce) does not satisfy it
+    from nbodysim_amd.comm import id_publish
+    id_publish(idf, 1, bytes(128))
+    late = subprocess.run([str(exe), *common, "-rank", "1", "-world", "2", "-idfile", str(idf), "-nonce", "2", "-deadline", "2"],
+                          capture_output=True, text=True, timeout=120)
+    assert late.returncode != 0 and "belongs to another launch" in late.stderr
+
+
+def test_c_loop_phases_add_up_to_the_step():
+    """nb_comm_profile / nb_comm_phase_read: HIP events inside the library's loop, one real rank through RCCL.  The phases
+    are consecutive intervals of the compute stream, so over a run that keeps the stream busy their sum is the step."""
+    import time
+    n, steps = 65536, 40
+    ic = nb.plummer_2d(n, 42)
+    for allreduce in (False, True):
+        with nb.Simulation(ic, eps=EPS, shard_rank=0, shard_world=1, shard_single=True, shard_allreduce=allreduce) as s:
+            with Comm.all([s]) as comm:
+                comm.step(5, DT)
+                comm.wait()
+                comm.profile(True)
+                t0 = time.perf_counter()
+                comm.step(steps, DT)
+                comm.wait()
+                wall_ms = (time.perf_counter() - t0) / steps * 1e3
+                ph = comm.phases(0)
+                assert ph["steps"] == steps
+                total = sum(ph[k] for k in L.NB_PH_NAMES)
+                assert abs(total - wall_ms) <= 0.05 * wall_ms, (ph, wall_ms)
+                if allreduce:
+                    assert ph["cross"] == 0.0 and ph["ag_wait"] == 0.0 and ph["local"] > 0.8 * total      # one launch of all pairs, then the all-reduce
+                else:
+                    assert ph["local"] > 0.8 * total                   # one rank: every pair is local
+                comm.profile(False)
+                comm.step(3, DT)                                       # profiling off again: no marks, still steps
+                comm.wait()
+                assert comm.phases(0)["steps"] == 0 and s.frame == 5 + steps + 3
+
+
+def test_one_rank_communicator_over_a_ragged_size(tmp_path):
+    """n that is neither a multiple of the tile nor of anything else: `nbody_main -shards 1 -rccl` and, in-process, three
+    ragged shards (ceil(n / 3) particles, a shorter last block) — same trajectory as the plain handle."""
+    exe = ROOT / "build" / "nbody_main"
+    a, b, c = tmp_path / "a.nbd", tmp_path / "b.nbd", tmp_path / "c.nbd"
+    common = ["-n", "10007", "-eps", "0.05"]
+    # the plain form runs 2 warm-up steps before its -s steps: 5 frames everywhere
+    for extra, out in ((["-s", "5", "-shards", "1", "-rccl"], a), (["-s", "5", "-shards", "3", "-no-symmetry"], b), (["-s", "3"], c)):
+        r = subprocess.run([str(exe), *common, *extra, "-dump", str(out)], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+    (ba, fa, _), (bb, fb, _), (bc, fc, _) = (nb.read_bodies(x) for x in (a, b, c))
+    assert fa == fb == fc == 5
+    assert np.max(np.abs(ba["pos"] - bc["pos"])) <= 2e-6 * np.max(np.abs(bc["pos"]))
+    assert np.max(np.abs(bb["pos"] - bc["pos"])) <= 2e-6 * np.max(np.abs(bc["pos"]))

@@ -293,9 +293,15 @@ def _c_driver_worker(rank, world, port, out_dir):
         sim.step(1e-3)
         k1, u1 = sim.energy()
         rep = sim.phase_report()
-        assert rep["steps"] == 5 and rep["host_enqueue"] > 0 and "driver" in rep
+        assert rep["steps"] == 5 and rep["host_enqueue"] > 0 and "driver" in rep and rep["phase_steps"] == 0
         mine = sim.sync().copy()
         assert sim.frame == 5
+        # attribution inside the library's loop: the same keys as the Python driver's report, timed by nb_comm_profile
+        sim.profile_phases(True)
+        sim.advance(6, 1e-3)
+        rep = sim.phase_report()
+        assert rep["phase_steps"] == 6 and rep["steps"] == 6 and rep["local"] > 0 and rep["remote_finish"] > 0
+        assert abs(rep["stream_total"] - (rep["local"] + rep["ag_wait"] + rep["remote_finish"])) < 1e-9
         np.save(Path(out_dir) / "pos.npy", mine["pos"])
         np.save(Path(out_dir) / "energy.npy", np.array([k0, u0, k1, u1]))
         sim.close()
