@@ -112,6 +112,12 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          mass spectrum with close heavy pairs turns into 6e-5 of the force scale (measured,
                                          tests/test_headline_gpu.py) for 2.5 % of kernel time.  Needs m > 0 everywhere and
                                          m_max^(3/2) / eps^3 inside the float range, else the flag is ignored (nb_describe tells) */
+       NB_FLAG_PIPELINE        = 64,  /* EXPERIMENTAL, off by default: whole-system fp32 2-D handles run nb_step's whole loop as ONE persistent
+                                         launch (sym_pipeline_f32: in-order ticket queue, per-tile counters where the launch boundaries were,
+                                         cooperative gathers) instead of two launches per step.  Same sums, bit-identical results — and
+                                         SLOWER on MI355X at every size measured (+3 % at N = 262 144, +60 ... +240 % below 65 536: every
+                                         in-launch hand-off costs 15-25 us of fence / atomic / poll latency, the two launch boundaries and the
+                                         dedicated gather launch it replaces cost ~21 us per step in all) */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange
@@ -474,6 +480,14 @@ int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out);
  * items_out receives up to cap items, local ones first, then cross, then late. */
 int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
                       nb_sym_item *items_out, size_t cap, nb_sym_info *info);
+
+/* Debugging aid for the persistent step pipeline (whole-system fp32 2-D handles run nb_step's loop as ONE launch): with watch
+ * on, every workgroup keeps a page-locked host word saying what it is doing (code << 56 | tile << 32 | ticket / step / piece;
+ * codes: 1 drew a ticket, 2 waits for a tile, 3 helps with a tile's gather, 4 item body, 5 arrived, 6 left, 7 gathers a piece);
+ * nb_debug_pipeline_state copies those words and the pipeline's device counters [queue head | done | summable | claim | fin |
+ * ready] (5 x tiles after the head) out while a launch is running. */
+int nb_debug_pipeline_watch(nb_sim *s, int on);
+int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t wg_cap, uint64_t *counters, size_t ctr_cap, uint32_t *tiles);
 
 /* Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) exactly as the device kernels evaluate it, on an array of n (even)
  * floats: y_scalar through the scalar form (reference-order kernel), y_packed through the packed form (tiled and

@@ -29,6 +29,7 @@ NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
 NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1, 2, 3
 NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE, NB_FLAG_SHARD_SINGLE, NB_FLAG_MASS_SCALING = 1, 2, 4, 8, 16, 32
+NB_FLAG_PIPELINE = 64
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(
@@ -204,6 +205,8 @@ PROTOTYPES = {
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_default_ics": (C.c_int, [C.c_void_p, C.c_size_t]),
     "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(nb_params), C.c_void_p, C.c_size_t, C.POINTER(nb_sym_info)]),
+    "nb_debug_pipeline_watch": (C.c_int, [C.c_void_p, C.c_int]),
+    "nb_debug_pipeline_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "nb_sym_plan_info": (C.c_int, [C.c_void_p, C.POINTER(nb_sym_info)]),
     "nb_last_error_code": (C.c_int, []),
     "nb_debug_fast_inv_sqrt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -43,6 +43,30 @@ template <typename real> struct vec2_of;
 template <> struct vec2_of<float> { typedef float2 type; };
 template <> struct vec2_of<double> { typedef double2 type; };
 
+// Stores of data that ANOTHER workgroup of the same launch will read (the persistent step pipeline, sym_pipeline_f32):
+// WT = write-through (`sc1`): the bytes leave this XCD's L2 for memory at once, so the publisher needs no agent-scope
+// release fence (a buffer_wbl2 per item cost the pipeline 25-65 us of workgroup time: profiles/r04_pipeline_ab_fences.log)
+// — only its own `s_waitcnt vmcnt(0)` before it signals (cdna_hip_programming.md Guideline 16, R1).  WT = false is the plain
+// store of the kernels whose results are consumed after a launch boundary.
+template <bool WT>
+__device__ __forceinline__ void store8(float2 *p, float2 v)
+{
+    if constexpr (WT) {
+        static_assert(sizeof(float2) == sizeof(unsigned long long), "8-byte element");
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else *p = v;
+}
+template <bool WT>
+__device__ __forceinline__ void store16(float4 *p, float4 v)
+{
+    if constexpr (WT) {
+        // one global_store_dwordx4 sc1; the compiler does not count stores inside asm: the callers drain with s_waitcnt vmcnt(0)
+        // before they signal; s_nop 1 = the wait states before the data registers may be rewritten (§5.7 of the HIP guide)
+        const v4f r = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(r) : "memory");
+    } else *p = v;
+}
+
 // ---------------------------------------------------------------------------
 // kick_drift_one — Simulation::iterate after attract(), Simulation.hpp:129-163, for ONE owned
 // particle whose summed acceleration is `a`: acc <- a; v += a dt; [clamp :133-137];
@@ -52,7 +76,7 @@ template <> struct vec2_of<double> { typedef double2 type; };
 // ---------------------------------------------------------------------------
 enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
 
-template <typename real, bool STRICT>
+template <typename real, bool STRICT, bool WT = false>
 __device__ __forceinline__
 void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
                     const typename vec2_of<real>::type *__restrict__ pos_cur,
@@ -62,7 +86,8 @@ void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
                     uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
 {
     typedef typename vec2_of<real>::type real2;
-    acc[li] = a;
+    static_assert(!WT || sizeof(real) == 4, "write-through stores: the fp32 pipeline only");
+    if constexpr (WT) store8<true>(&acc[li], a); else acc[li] = a;
     if (!(flags & INTEG_KICK)) return;              // acceleration gather only
     real2 v = vel[li];
     const real2 x = pos_cur[i_begin + li];
@@ -99,7 +124,7 @@ void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
             v.y *= (real)0.9995f;
         }
     }
-    vel[li] = v;
+    if constexpr (WT) store8<true>(&vel[li], v); else vel[li] = v;
     if (flags & INTEG_DRIFT) {
         real2 xn;
         if constexpr (STRICT) {
@@ -110,7 +135,7 @@ void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
             xn.x = __builtin_fma(v.x, dt_drift, x.x);
             xn.y = __builtin_fma(v.y, dt_drift, x.y);
         }
-        pos_next[i_begin + li] = xn;
+        if constexpr (WT) store8<true>(&pos_next[i_begin + li], xn); else pos_next[i_begin + li] = xn;
     }
 }
 
@@ -443,7 +468,7 @@ enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
 // WS (wave split, force_sym_f32<..., WS = true>): the 4 waves of the workgroup hold the SAME stationary particles and
 // take the item's chunks in turn (wave w: chunks w, w + 4, ...), so a travelling partial is complete inside ONE wave
 // and is stored straight from the registers: no LDS combine, no barrier per chunk.
-template <int RSQ, int MM, bool DIAG, bool WS = false>
+template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -540,7 +565,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
             if constexpr (MS) { const float s2 = mq * mq; r.x *= s2; r.y *= s2; }      // / m_j: the particle is back in its home lane
             if constexpr (WS) {
                 const uint32_t j = (c0 + c) * SYM_CH + lane;      // this wave alone met the chunk: its sum is the partial
-                if (j < n) slab_r_row[j] = r;
+                if (j < n) store8<WT>(&slab_r_row[j], r);
             } else {
                 float2 (*rb)[64] = red[c & 1u];
                 rb[w][lane] = r;
@@ -550,7 +575,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
                     float2 a = rb[0][lane];
 #pragma unroll
                     for (int k = 1; k < 4; ++k) { a.x += rb[k][lane].x; a.y += rb[k][lane].y; }
-                    if (j < n) slab_r_row[j] = a;
+                    if (j < n) store8<WT>(&slab_r_row[j], a);
                 }
             }
         }
@@ -571,7 +596,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
 // The stationary accumulators become per-particle pairs {from q0, from q1} (32 registers instead of 16), summed at the
 // end.  An odd chunk count leaves the second half of the last pair empty (PAD particles: half of that pair's work is
 // wasted), so the planner cuts items into even chunk counts for handles that run this kernel (SymTuning::even_chunks).
-template <int RSQ, int MM, bool DIAG, bool WS = false>
+template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
                  float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -658,8 +683,8 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
             if constexpr (UM) { r.x *= um_mass; r.y *= um_mass; r.z *= um_mass; r.w *= um_mass; }
             if constexpr (WS) {
                 const uint32_t j0 = (c0 + c) * SYM_CH + lane, j1 = j0 + SYM_CH;
-                if (j0 < n) slab_r_row[j0] = make_float2(r.x, r.y);
-                if (c + 1 < cnt && j1 < n) slab_r_row[j1] = make_float2(r.z, r.w);
+                if (j0 < n) store8<WT>(&slab_r_row[j0], make_float2(r.x, r.y));
+                if (c + 1 < cnt && j1 < n) store8<WT>(&slab_r_row[j1], make_float2(r.z, r.w));
             } else {
                 float4 (*rb)[64] = red[(c >> 1) & 1u];
                 rb[w][lane] = r;
@@ -672,7 +697,7 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
                         a.x += w ? rb[k][lane].z : rb[k][lane].x;
                         a.y += w ? rb[k][lane].w : rb[k][lane].y;
                     }
-                    if (j < n) slab_r_row[j] = a;
+                    if (j < n) store8<WT>(&slab_r_row[j], a);
                 }
             }
         }
@@ -692,10 +717,10 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
 // cross-wave combine (no barrier inside the sweep), and an item's stationary row is 4 KiB instead of 16.  The four
 // waves' stationary sums are added once, at the end, through LDS in wave order.  Price: four times the travelling
 // partials per pair (one per 512 x 64 instead of 2048 x 64 pairs), which is why large systems keep the classic form.
-template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
-                        const SymItem *__restrict__ items,
+                        const SymItem it,
                         float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
                         uint32_t n, float eps2, float um_mass)
 {
@@ -706,7 +731,6 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
     __shared__ float4 red4[WS ? 4 * SYM_P : 2 * 4][64];          // classic: [2][4][64] chunk combine; WS: [4 waves][SYM_P][64] final sums
     float2 (*red)[4][64] = reinterpret_cast<float2 (*)[4][64]>(red4);
     float4 (*red2)[4][64] = reinterpret_cast<float4 (*)[4][64]>(red4);
-    const SymItem it = items[blockIdx.x];
     const bool diag = it.diag != 0;
     const uint32_t s_row = it.s_row;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
@@ -727,11 +751,11 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
     }
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
     if constexpr (PAIRS) {
-        if (diag) sym_chunks2<RSQ, MM, true, WS>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
-        else      sym_chunks2<RSQ, MM, false, WS>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
+        if (diag) sym_chunks2<RSQ, MM, true, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
+        else      sym_chunks2<RSQ, MM, false, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
     } else {
-        if (diag) sym_chunks<RSQ, MM, true, WS>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
-        else      sym_chunks<RSQ, MM, false, WS>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        if (diag) sym_chunks<RSQ, MM, true, WS, WT>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        else      sym_chunks<RSQ, MM, false, WS, WT>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     }
 
     float2 *__restrict__ out = slab_s + (size_t)s_row * SB;
@@ -745,12 +769,12 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
 #pragma unroll
         for (int k = 1; k < 4; ++k) { const float4 b = red4[k * SYM_P + w][lane]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
         if constexpr (UM) { a.x *= um_mass; a.y *= um_mass; a.z *= um_mass; a.w *= um_mass; }
-        *reinterpret_cast<float4 *>(&out[w * 128u + 2u * lane]) = a;
+        store16<WT>(reinterpret_cast<float4 *>(&out[w * 128u + 2u * lane]), a);
     } else {
 #pragma unroll
         for (int p = 0; p < SYM_P; ++p) {
             if constexpr (UM) { ax[p] *= um_mass; ay[p] *= um_mass; }
-            *reinterpret_cast<float4 *>(&out[li[p]]) = make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y);
+            store16<WT>(reinterpret_cast<float4 *>(&out[li[p]]), make_float4(ax[p].x, ay[p].x, ax[p].y, ay[p].y));
         }
     }
 }
@@ -762,7 +786,11 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
                    float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
                    uint32_t n, float eps2, float um_mass)
 {
-    force_sym_f32_body<RSQ, MM, PAIRS, WS>(pos, mass, sigma, items, slab_s, slab_r, n, eps2, um_mass);
+#ifndef NB_SYM_WT
+#define NB_SYM_WT true       // write-through (sc1) slab stores: the partials are read by the NEXT launch only, so nothing is gained by
+#endif                       // keeping them dirty in this XCD's L2 until the kernel's end flushes them: -1.8 % step time at N = 25 000,
+                             // -0.7 % at 65 536, neutral at 262 144, same bits (tools/wt_ab.sh, profiles/r04_write_through_ab.log)
+    force_sym_f32_body<RSQ, MM, PAIRS, WS, NB_SYM_WT>(pos, mass, sigma, items[blockIdx.x], slab_s, slab_r, n, eps2, um_mass);
 }
 
 // sigma[i] = m_i^(-1/2) for the mass-scaled kernels (correctly rounded sqrt and divide)
@@ -801,9 +829,10 @@ __device__ __forceinline__ void load_pair(const double2 *__restrict__ p, double2
 // wave-split plans); tile g's stationary rows are
 // [row_lo[g], row_hi[g]), its coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).  Segment bounds are
 // multiples of 64 (or n) and segment offsets even (nb_plan.cpp), so a pair (k, k + 1), k even, is covered together.
-template <typename real, bool FUSE>
-__global__ __launch_bounds__(BLOCK)
-void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
+template <typename real, bool FUSE, bool WT = false>
+__device__ __forceinline__
+void sym_gather_block(uint32_t blk,
+                const typename vec2_of<real>::type *__restrict__ slab_s,
                 const typename vec2_of<real>::type *__restrict__ slab_r,
                 const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
                 const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov,
@@ -819,7 +848,7 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     typedef typename vec2_of<real>::type real2;
     __shared__ real2 part[GATHER_Q][GATHER_P];
     const uint32_t p = threadIdx.x % GATHER_T, q = threadIdx.x / GATHER_T;
-    const uint32_t li = blockIdx.x * GATHER_P + 2u * p, k = k0 + li;
+    const uint32_t li = blk * GATHER_P + 2u * p, k = k0 + li;
     real2 a0, a1; a0.x = a0.y = a1.x = a1.y = 0;
     if (li < kn) {
         const uint32_t g = k >> sb_shift, loc = k & ((1u << sb_shift) - 1u);
@@ -844,15 +873,258 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
     part[q][2u * p + 1] = a1;
     __syncthreads();
     // thread t < 64 finishes particle t of the workgroup
-    const uint32_t f = threadIdx.x, lf = blockIdx.x * GATHER_P + f;
+    const uint32_t f = threadIdx.x, lf = blk * GATHER_P + f;
     if (f < (uint32_t)GATHER_P && lf < kn) {
         real2 t = part[0][f];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][f].x; t.y += part[j][f].y; }
         if (base) { const real2 bb = base[lf]; t.x += bb.x; t.y += bb.y; }
-        if constexpr (FUSE) kick_drift_one<real, false>(t, lf, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
+        if constexpr (FUSE) kick_drift_one<real, false, WT>(t, lf, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
         else acc_sum[k0 + lf] = t;
     }
+}
+
+template <typename real, bool FUSE>
+__global__ __launch_bounds__(BLOCK)
+void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
+                const typename vec2_of<real>::type *__restrict__ slab_r,
+                const uint32_t *__restrict__ row_lo, const uint32_t *__restrict__ row_hi,
+                const uint32_t *__restrict__ cov_begin, const SymCov *__restrict__ cov,
+                uint32_t n, uint32_t k0, uint32_t kn,
+                typename vec2_of<real>::type *__restrict__ acc_sum,
+                const typename vec2_of<real>::type *__restrict__ base,
+                const typename vec2_of<real>::type *__restrict__ pos_cur,
+                typename vec2_of<real>::type *__restrict__ pos_next,
+                typename vec2_of<real>::type *__restrict__ vel,
+                typename vec2_of<real>::type *__restrict__ acc,
+                real dt_kick, real dt_drift, int extras, int flags, uint32_t sb_shift)
+{
+    sym_gather_block<real, FUSE>(blockIdx.x, slab_s, slab_r, row_lo, row_hi, cov_begin, cov, n, k0, kn, acc_sum, base, pos_cur, pos_next, vel, acc,
+                                 dt_kick, dt_drift, extras, flags, sb_shift);
+}
+
+// ---------------------------------------------------------------------------
+// sym_pipeline_f32 — the whole step LOOP of a single handle as ONE persistent launch.
+//
+// What it replaces: per step, force_sym_f32 (one workgroup per item) + sym_gather (sum of the slabs, kick, drift) — two
+// dependent launches whose boundaries, fill and drain cost a short step a quarter of its time (N = 25 000: 74 us of VALU
+// work at the clock the part holds, 111 us per step; tools/sym_timeline.hip, profiles/r04_sym_timeline.log).  Here
+// `grid` resident workgroups draw (step, item) tickets from ONE in-order queue and run the SAME item body; what a
+// launch boundary used to order is ordered by per-TILE counters instead (all monotonic over the handle's life):
+//   done[g]      arrivals at tile g: every finished item adds one to each tile it touched (its stationary tile and the
+//                tiles its travelling chunks lie in).  The add that completes expected[g] x (step + 1) makes its
+//                workgroup the LAST ARRIVER of tile g for that step: it publishes
+//   summable[g]  = step + 1: every partial sum of the tile for that step is in memory.  The tile's gather — the sums
+//                of sym_gather, in its order and association, then kick and drift — is cut into 64-particle PIECES
+//                (one sym_gather workgroup's work each) that are CLAIMED one by one (claim[g], compare-and-swap: no
+//                claim beyond the step's pieces) by the last arriver AND by every workgroup that is waiting for the
+//                tile: who needs a tile helps to finish it, so the gather at the end of a step — the one thing every
+//                item of the next step waits for — is a few microseconds of many workgroups, not 100+ us of one.
+//   fin[g]       pieces finished; the workgroup that finishes the step's last piece publishes
+//   ready[g]     = number of steps tile g's positions have been advanced.  An item of step k starts once ready[] >= k
+//                for the tiles it touches.
+// Why that is enough, with the slabs and position replicas SINGLE / DOUBLE buffered as before: an item's outputs (its
+// stationary row, its travelling partials) are read only by the gathers of the tiles it touches — exactly the gathers
+// it waits for; the replica a gather of step k writes was last read by step k - 1's items touching that tile, all of
+// which arrived before the step k - 1 gather that this step's items waited for.
+// Progress: tickets are drawn in order and an item waits only for gathers of EARLIER tickets' steps, whose items are
+// running or finished and whose pieces any waiter can complete itself — no cycle, whatever the placement; every
+// workgroup leaves when the queue is empty.  A wait that does not end within PIPE_TIMEOUT (a bug, never a legal state)
+// sets *err and every workgroup drains: the host reports NB_EHIP and refuses the handle, the GPU is never left spinning.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): producer =
+// WRITE-THROUGH (sc1) stores of every handed-off byte (store8 / store16 <WT>) -> every wave s_waitcnt vmcnt(0) -> barrier ->
+// lane 0 agent-scope atomic (no release fence: a buffer_wbl2 per item cost 25-65 us of workgroup time); consumer = relaxed
+// agent poll / ticket -> lane 0 agent ACQUIRE fence -> s_waitcnt vmcnt(0) -> barrier -> plain vector loads.
+// The sums keep sym_gather's association, so the trajectory is BIT-IDENTICAL to the two-launch path
+// (tests/test_pipeline_gpu.py) — which is also how a stale read would show.
+// ---------------------------------------------------------------------------
+typedef unsigned long long u64_t;
+constexpr u64_t PIPE_TIMEOUT_TICKS = 400000000ull;       // 4 s of the 100 MHz real-time counter
+enum { PIPE_GO = 0, PIPE_HELP = 1, PIPE_FAIL = 2 };
+
+struct PipeArgs {
+    const float2 *pos[2];            // replica read by even / odd local steps is pos[(cur0 + step) & 1]
+    float2 *pos_w[2];                // the same two buffers, writable
+    const float *mass, *sigma;
+    const SymItem *items;
+    const uint32_t *order;           // ticket i of a step runs item order[i] (see PIPE ORDER below)
+    float2 *slab_s, *slab_r;
+    const uint32_t *row_lo, *row_hi, *cov_begin;
+    const SymCov *cov;
+    const uint32_t *expected;        // items touching each tile
+    float2 *vel, *acc;
+    u64_t *head, *done, *summable, *claim, *fin, *ready;     // ticket counter; per-tile counters (see above)
+    int *err;
+    u64_t *dbg;                      // optional (nb_debug_pipeline_watch): page-locked host words, one per workgroup: what it is doing now
+    uint32_t n, n_items, tiles, sb_shift, steps, cur0;
+    u64_t epoch0, ticket0;           // steps / tickets this handle's pipeline had completed before the launch
+    float eps2, um_mass, dt;
+    int extras;
+};
+
+__device__ __forceinline__ u64_t pipe_load(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// what this workgroup is doing, for a host that watches a launch (debugging aid; a.dbg is NULL otherwise): code << 56 | tile << 32 | low word
+enum { PIPE_DBG_TICKET = 1, PIPE_DBG_WAIT = 2, PIPE_DBG_HELP = 3, PIPE_DBG_BODY = 4, PIPE_DBG_ARRIVED = 5, PIPE_DBG_EXIT = 6, PIPE_DBG_PIECE = 7 };
+__device__ __forceinline__ void pipe_dbg(const PipeArgs &a, uint32_t code, uint32_t g, uint32_t low)
+{
+    if (a.dbg && threadIdx.x == 0)
+        __hip_atomic_store(a.dbg + blockIdx.x, ((u64_t)code << 56) | ((u64_t)(g & 0xffffffu) << 32) | low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// All threads.  Help to finish the gather of tile g for absolute step j (its sums are summable): claim 64-particle pieces
+// until none of the step's pieces is left, sum + kick + drift each, count it finished; whoever finishes the last one
+// publishes ready[g] = j + 1.  sh is one LDS word of the caller.
+__device__ __forceinline__ void pipe_help_tile(const PipeArgs &a, uint32_t g, u64_t j, uint32_t *sh)
+{
+    const uint32_t t = threadIdx.x;
+    const u64_t pieces = (1ull << a.sb_shift) / (u64_t)GATHER_P, first = pieces * j, last = first + pieces;
+    const bool odd = ((a.cur0 + (uint32_t)(j - a.epoch0)) & 1u) != 0;
+    const float2 *__restrict__ pos_cur = odd ? a.pos[1] : a.pos[0];
+    float2 *__restrict__ pos_next = odd ? a.pos_w[0] : a.pos_w[1];
+    if (t == 0) {                                            // the slabs were published before summable[g] was: ONE acquire per session
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    pipe_dbg(a, PIPE_DBG_HELP, g, (uint32_t)j);
+    // ONE lane-0 block per turn (count the piece just finished, then claim the next): with a lane-0 block at the end of
+    // the body as well, the compiler threaded the two across the back edge and nested the loop so that lanes 1-63 of
+    // wave 0 span for ever on a word only the parked lane 0 could change (found with nb_debug_pipeline_watch)
+    uint32_t prev = 0xffffffffu;
+    for (;;) {
+        if (t == 0) {
+            if (prev != 0xffffffffu) {
+                const u64_t f = __hip_atomic_fetch_add(a.fin + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f + 1 == last) __hip_atomic_store(a.ready + g, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            u64_t c = pipe_load(a.claim + g);
+            uint32_t piece = 0xffffffffu;
+            for (uint32_t tries = 0; c >= first && c < last; ++tries) {
+                if (__hip_atomic_compare_exchange_strong(a.claim + g, &c, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    piece = (uint32_t)(c - first);
+                    break;
+                }
+                if (tries > 100000u) { __hip_atomic_store(a.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // every loop of this kernel is bounded
+            }
+            *sh = piece;
+        }
+        __syncthreads();
+        // every loop-control value of this kernel is made PROVABLY wave-uniform (readfirstlane): the branches are scalar
+        const uint32_t piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)*sh);
+        if (piece == 0xffffffffu) break;
+        pipe_dbg(a, PIPE_DBG_PIECE, g, piece);
+        sym_gather_block<float, true, true>((g << a.sb_shift) / (uint32_t)GATHER_P + piece, a.slab_s, a.slab_r, a.row_lo, a.row_hi, a.cov_begin, a.cov,
+                                            a.n, 0u, a.n, nullptr, nullptr, pos_cur, pos_next, a.vel, a.acc, a.dt, a.dt, a.extras,
+                                            INTEG_KICK | INTEG_DRIFT, a.sb_shift);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's write-through stores of x, v, a have left
+        __syncthreads();                                    // ... every wave's: lane 0 may count the piece; *sh and the gather's LDS may be rewritten
+        prev = piece;
+    }
+    __syncthreads();
+}
+
+// All threads.  Until tile g has been advanced to step k (ready[g] >= k); while its last gather is summable but unfinished,
+// help with it.  False if the launch has been given up.
+__device__ __forceinline__ bool pipe_wait_tile(const PipeArgs &a, uint32_t g, u64_t k, uint32_t *sh)
+{
+    const uint32_t t = threadIdx.x;
+    pipe_dbg(a, PIPE_DBG_WAIT, g, (uint32_t)k);
+    for (uint32_t rounds = 0;; ++rounds) {
+        if (t == 0) {
+            uint32_t st = PIPE_GO;
+            if (rounds > 100000u) {                         // helping that never gets anywhere: a bug; every loop of this kernel is bounded
+                __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st = PIPE_FAIL;
+            } else if (pipe_load(a.ready + g) < k) {
+                const u64_t t0 = __builtin_amdgcn_s_memrealtime();
+                for (uint32_t spins = 1;; ++spins) {
+                    if (pipe_load(a.ready + g) >= k) { st = PIPE_GO; break; }
+                    if (pipe_load(a.summable + g) >= k && pipe_load(a.claim + g) < ((1ull << a.sb_shift) / (u64_t)GATHER_P) * k) { st = PIPE_HELP; break; }
+                    __builtin_amdgcn_s_sleep(32);           // ~1 us between polls: hundreds of workgroups may be waiting (polling-cost, MI355X_MICROARCH.md)
+                    if ((spins & 63u) != 0u) continue;      // the give-up word and the clock: every 64th poll
+                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { st = PIPE_FAIL; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > PIPE_TIMEOUT_TICKS) {
+                        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st = PIPE_FAIL;
+                        break;
+                    }
+                }
+            }
+            *sh = st;
+        }
+        __syncthreads();
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)*sh);
+        __syncthreads();                                    // *sh is rewritten below / by the next poll
+        if (st == PIPE_GO) return true;
+        if (st == PIPE_FAIL) return false;
+        pipe_help_tile(a, g, k - 1, sh);                    // unclaimed pieces of the step before: take some, then look again
+    }
+}
+
+// Occupancy is pinned to what the item body gets as a kernel of its own (4 waves per SIMD, 3 with chunk pairs): without
+// the bound the allocator lets the general-mass pair variants grow to 248 VGPRs (2 waves per SIMD).
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
+__global__ __launch_bounds__(BLOCK, (PAIRS ? 3 : 4))
+void sym_pipeline_f32(const PipeArgs a)
+{
+    __shared__ u64_t sh_ticket;
+    __shared__ uint32_t sh_word, sh_mask;
+    const uint32_t t = threadIdx.x;
+    const u64_t total = (u64_t)a.steps * a.n_items;
+    for (;;) {
+        if (t == 0) sh_ticket = __hip_atomic_fetch_add(a.head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket0;
+        __syncthreads();
+        const u64_t q = ((u64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sh_ticket >> 32)) << 32) |
+                        (u64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sh_ticket);
+        pipe_dbg(a, PIPE_DBG_TICKET, 0u, (uint32_t)q);
+        if (q >= total) break;                              // the queue is empty: every workgroup gets here
+        const uint32_t step = (uint32_t)(q / a.n_items), i = (uint32_t)(q % a.n_items);
+        const u64_t k = a.epoch0 + step;                    // absolute step of this handle's pipeline
+        const SymItem it = a.items[a.order[i]];
+        const uint32_t lastp = min((it.c0 + it.cnt) * SYM_CH, a.n) - 1u;
+        const uint32_t t_lo = it.diag ? it.tile : (it.c0 * SYM_CH) >> a.sb_shift, t_hi = it.diag ? it.tile : lastp >> a.sb_shift;
+        // ---- wait until the tiles this item reads have been advanced to step k (helping with their gathers), then ONE acquire
+        bool ok = pipe_wait_tile(a, it.tile, k, &sh_word);
+        if (!it.diag) for (uint32_t g = t_lo; ok && g <= t_hi; ++g) ok = pipe_wait_tile(a, g, k, &sh_word);
+        if (!ok) break;                                     // the launch has been given up (time-out somewhere): drain
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const bool odd = ((a.cur0 + step) & 1u) != 0;
+        const float2 *__restrict__ pos_cur = odd ? a.pos[1] : a.pos[0];
+        pipe_dbg(a, PIPE_DBG_BODY, it.tile, (uint32_t)q);
+        force_sym_f32_body<RSQ, MM, PAIRS, WS, true>(pos_cur, a.mass, a.sigma, it, a.slab_s, a.slab_r, a.n, a.eps2, a.um_mass);
+        // ---- publish: the slab stores are write-through; every wave drains its own, then ONE lane adds one arrival per tile touched
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            // bit 0: the stationary tile; bit 1 + j: tile t_lo + j of the travelling chunks (the host runs the pipeline only
+            // for plans whose items span at most 31 tiles)
+            uint32_t mask = 0;
+            const u64_t want = k + 1;
+            auto arrive = [&](uint32_t g, uint32_t bit) {
+                const u64_t old = __hip_atomic_fetch_add(a.done + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1 == (u64_t)a.expected[g] * want) {
+                    __hip_atomic_store(a.summable + g, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // waiters may start on the pieces at once
+                    mask |= 1u << bit;
+                }
+            };
+            arrive(it.tile, 0u);
+            if (!it.diag) for (uint32_t g = t_lo; g <= t_hi; ++g) arrive(g, 1u + g - t_lo);
+            sh_mask = mask;
+        }
+        pipe_dbg(a, PIPE_DBG_ARRIVED, it.tile, (uint32_t)q);
+        __syncthreads();
+        for (uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_mask); mask; mask &= mask - 1u) {
+            // last arriver of tile g: take whatever pieces of its gather nobody else has claimed yet
+            const uint32_t bit = (uint32_t)__builtin_ctz(mask);
+            pipe_help_tile(a, bit == 0u ? it.tile : t_lo + bit - 1u, k, &sh_word);
+        }
+        __syncthreads();                                    // sh_ticket / sh_mask are rewritten by the next turn
+    }
+    pipe_dbg(a, PIPE_DBG_EXIT, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------

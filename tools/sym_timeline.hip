@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
 void stamped(const float2 *pos, const float *mass, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
-    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items, slab_s, slab_r, n, eps2, um);
+    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items[blockIdx.x], slab_s, slab_r, n, eps2, um);
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) {
         Stamp s;
