@@ -192,6 +192,35 @@ def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler
     return {"steps": done, "seconds": el, "ms_per_step": el / done * 1e3, "device_state": smp.stop()}
 
 
+def kernel_instantiation(desc, precision, dims, rsqrt):
+    """The exact template instantiation of the dominant force kernel as rocprofv3 prints it, from nb_describe's fields —
+    what a PMC record must name to be THIS run's kernel (None for the kernels no PMC set is kept for)."""
+    f = dict(kv.split("=", 1) for kv in desc.replace("|", " ").split() if "=" in kv)
+    if precision != "fp32" or dims != 2 or f.get("symmetric") != "1" or f.get("pipeline") == "1":
+        return None
+    mm = 0 if f.get("uniform_mass") == "1" else 2 if f.get("mass_scaled") == "1" else 1
+    b = lambda v: "true" if v else "false"
+    return f"nbk::force_sym_f32<{1 if rsqrt == 'quake' else 0}, {mm}, {b(f.get('chunk_pairs') == '1')}, {b(f.get('tile') == '512')}>"
+
+
+def pmc_lookup(book, kernel_full, n, items):
+    """The PMC record (profiles/hbm_traffic.json, written by tools/summarize_profile.py) of EXACTLY the kernel that ran:
+    same template instantiation, same N, same number of work items (= same plan: chunks per item, tile, tail).  Returns
+    (entry or None, status): "match", "stale: ..." (records exist for this N but for another kernel / plan: a kernel change
+    or other tuning since the counters were taken), or "none"."""
+    entries = (book or {}).get("entries") or []
+    if kernel_full is None:
+        return None, "none: no PMC set is kept for this kernel"
+    same_n = [e for e in entries if e.get("n") == n]
+    for e in same_n:
+        if e.get("kernel") == kernel_full and e.get("grid_workgroups") in (None, 0, items):
+            return e, "match"
+    if same_n:
+        have = ", ".join(f"{e.get('kernel')} x {e.get('grid_workgroups')} items @ {e.get('commit')}" for e in same_n)
+        return None, f"stale: this run's kernel is {kernel_full} x {items} items; the PMC records for N = {n} are of: {have}"
+    return None, "none"
+
+
 def cpu_baseline(ic, n, target_s=10.0):
     """The CPU figures beside the GPU number, on a bounded i-slice of the same workload (all n j-particles):
     * kind "reference" — the compiled reference's OWN pairwise loop (Quadtree::acc, Quadtree.hpp:113-155, driven as a
@@ -485,15 +514,19 @@ def main() -> None:
         # partials once (plain stores, no re-reads); the positions (and masses) are read from HBM once, later reads hit L2
         esz = (8 if args.precision == "fp32" else 16) * (2 if args.dims == 3 else 1)
         traffic = float(info["slab_s_bytes"] + info["slab_r_bytes"] + n * esz) if (symmetric and world == 1) else None
-        pmc = {}
+        book = {}
         tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived (tools/gpu_round.sh pmc + tools/summarize_profile.py)
         if tfile.exists() and world == 1:
             try:
-                pmc = json.loads(tfile.read_text())
+                book = json.loads(tfile.read_text())
             except Exception:
-                pmc = {}
-        pmc_ok = bool(pmc) and pmc.get("n", N_DEFAULT) == n and (kernel + "<") in pmc.get("kernel", "") and args.dims == 2
+                book = {}
+        kernel_full = kernel_instantiation(inner.describe(), args.precision, args.dims, args.rsqrt) if world == 1 else None
+        pmc, pmc_status = pmc_lookup(book, kernel_full, n, info["items"])
+        pmc_ok = pmc is not None
+        pmc = pmc or {}
         traffic_pmc = pmc.get("force_kernel_hbm_bytes_per_launch") if pmc_ok else None
+        traffic_reported = traffic_pmc if traffic_pmc else traffic           # ONE figure: `traffic`, the bandwidth and the intensity below use it
         if world == 1:
             workload = (f"N={n} {args.precision} direct O(N^2), one MI355X, kernel {kernel}: "
                         + (f"symmetric pair items ({info['items']} workgroups x {info['chunks_per_item']} chunks of 64, stationary particles in "
@@ -543,7 +576,10 @@ def main() -> None:
                 "valu_busy": pmc.get("valu_busy") if pmc_ok else None,
                 "valu_busy_source": ("profiles/hbm_traffic.json: a separate rocprofv3 --pmc run of this command on ANOTHER MI355X box, "
                                      "not a measurement of this run") if pmc_ok else None,
-                "traffic": traffic_pmc if traffic_pmc else traffic,
+                "pmc_status": pmc_status,
+                "pmc_commit": pmc.get("commit") if pmc_ok else None,
+                "kernel_instantiation": kernel_full,
+                "traffic": traffic_reported,
                 "traffic_source": ("PMC: profiles/hbm_traffic.json (separate rocprofv3 --pmc passes of this command on an MI355X: FETCH_SIZE x2 "
                                    "+ WRITE_SIZE per launch of the force kernel); the plan-derived figure is traffic_plan"
                                    if traffic_pmc else
@@ -571,8 +607,8 @@ def main() -> None:
                         "algorithmic HBM bytes are 36 B per particle-step, ~1e5 flop/B: HBM is not the bound, the slab traffic is the "
                         "price of evaluating every pair once with plain stores (no atomics, bit-reproducible)",
                 "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
-                "plan_hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
-                "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic) if traffic else None,
+                "kernel_hbm_gbps": (traffic_reported / (avg_launch_ms * 1e-3) / 1e9) if (traffic_reported and avg_launch_ms) else None,
+                "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic_reported) if traffic_reported else None,
             },
             "device_state": device_state,
             "sustained": ({**sustained, "value": float(n) * float(n) * sustained["steps"] / sustained["seconds"],

@@ -111,7 +111,12 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          difference of two floats (relative error 6e-8 |x| / |d| per pair force), which a broad
                                          mass spectrum with close heavy pairs turns into 6e-5 of the force scale (measured,
                                          tests/test_headline_gpu.py) for 2.5 % of kernel time.  Needs m > 0 everywhere and
-                                         m_max^(3/2) / eps^3 inside the float range, else the flag is ignored (nb_describe tells) */
+                                         m_max^(3/2) / eps^3 inside the float range, else the flag is ignored (nb_describe tells).
+                                         SELF TERM: with the masses in the geometry a body's pair with ITSELF no longer cancels exactly
+                                         (its displacement is the rounding residue of sigma x, not 0): every body gets a spurious
+                                         acceleration of up to 6e-8 |x| m / eps^3 — 0.06 |x| m at eps = 0.01, growing as eps^-3 — and the
+                                         total momentum is conserved to that level only, not to rounding (measured in
+                                         tests/test_headline_gpu.py); one more reason the flag is opt-in */
        NB_FLAG_PIPELINE        = 64,  /* EXPERIMENTAL, off by default: whole-system fp32 2-D handles run nb_step's whole loop as ONE persistent
                                          launch (sym_pipeline_f32: in-order ticket queue, per-tile counters where the launch boundaries were,
                                          cooperative gathers) instead of two launches per step.  Same sums, bit-identical results — and

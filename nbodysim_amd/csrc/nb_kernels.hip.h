@@ -463,6 +463,9 @@ __device__ __forceinline__ float lane_rot(float v, int addr)
 //               Price: D is no longer an exact difference of two floats (X_j is rounded once: relative error
 //               6e-8 |x_j| / |d| of the pair's force), and m must be positive with m_max^(3/2) / eps^3 and 1 / m_min
 //               inside the float range — checked at upload (nb_capi.hip: mass_scaling_ok), otherwise MM_GENERAL runs.
+//               The pair of a body with ITSELF (diagonal items) does not cancel either: D = fma(-sigma, x, round(sigma x)) is
+//               the rounding residue, so g^3 D is a spurious self-acceleration of up to 6e-8 |x| m / eps^3 and momentum is
+//               conserved to that level only (include/nbody.h, NB_FLAG_MASS_SCALING).
 enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
 
 // WS (wave split, force_sym_f32<..., WS = true>): the 4 waves of the workgroup hold the SAME stationary particles and

@@ -39,7 +39,10 @@ def test_bench_line_contract():
     assert rf["kernel"] == "force_sym_f32" and rf["kernel"] in d["config"]["workload"] and "LDS tile" not in d["config"]["workload"]
     assert 0 < rf["executed_frac"] < rf["frac"] and abs(rf["executed_frac"] - rf["executed_tflops"] / rf["peak"]) < 1e-9
     assert abs(rf["executed_frac"] / rf["frac"] - 17.0 / 28.0) < 0.04             # 17 flop per unordered pair vs 2 x 14 algorithmic (+ the one-sided diagonal items)
-    assert rf["traffic"] > 36 * 32768 and rf["traffic_pmc"] is None and rf["traffic"] == rf["traffic_plan"]   # the PMC file is for N = 262 144 only
+    assert rf["traffic"] > 36 * 32768 and rf["traffic_pmc"] is None and rf["traffic"] == rf["traffic_plan"]   # no PMC record is kept for N = 32 768
+    # PMC provenance: the line names the exact instantiation that ran; counter figures appear only with a record of exactly it
+    assert rf["kernel_instantiation"] == "nbk::force_sym_f32<0, 0, false, true>" and rf["pmc_status"] == "none" and rf["pmc_commit"] is None
+    assert rf["valu_busy"] is None and abs(rf["arithmetic_intensity_flop_per_byte"] - 14.0 * 32768.0 ** 2 / rf["traffic"]) < 1e-6 * rf["arithmetic_intensity_flop_per_byte"]
     g = rf["general_mass"]
     assert g["avg_launch_ms"] > rf["avg_launch_ms"] and 0 < g["frac"] < rf["frac"]   # individual masses: 12 + 2 ops per body
     assert {"nproc", "affinity", "cgroup_cpus", "model"} <= set(d["cpu_baseline"]["host"])

@@ -42,3 +42,28 @@ def test_host_description_and_sampler_without_a_gpu():
     s.start()
     out = s.stop()
     assert out is None or {"power_w_mean", "sclk_mhz_mean", "samples"} <= set(out)
+
+
+def test_pmc_figures_are_reported_only_for_the_kernel_that_ran():
+    """roofline.valu_busy / traffic_pmc come from profiles/hbm_traffic.json: a record is used only if it names the exact
+    template instantiation, N and item count of this run; records of another kernel or plan at the same N read "stale"."""
+    b = load_bench()
+    desc = ("n=262144 owned=[0,+262144) fp32 rsqrt=exact sum=tiled | force: block=256 | uniform_mass=1 mass_scaled=0 | "
+            "symmetric=1 pipeline=0 tile=2048 chunk_pairs=1 items=8187 chunks/item=44 late=0 slabs=1.0+1.0 MiB | CUs=256")
+    k = b.kernel_instantiation(desc, "fp32", 2, "exact")
+    assert k == "nbk::force_sym_f32<0, 0, true, false>"
+    assert b.kernel_instantiation(desc.replace("uniform_mass=1", "uniform_mass=0"), "fp32", 2, "quake") == "nbk::force_sym_f32<1, 1, true, false>"
+    assert b.kernel_instantiation(desc.replace("tile=2048", "tile=512").replace("chunk_pairs=1", "chunk_pairs=0"), "fp32", 2, "exact") == "nbk::force_sym_f32<0, 0, false, true>"
+    assert b.kernel_instantiation(desc, "fp64", 2, "exact") is None and b.kernel_instantiation(desc.replace("symmetric=1", "symmetric=0"), "fp32", 2, "exact") is None
+    book = {"entries": [{"kernel": k, "n": 262144, "grid_workgroups": 8187, "commit": "abc", "valu_busy": 0.95, "force_kernel_hbm_bytes_per_launch": 3.0e8},
+                        {"kernel": "nbk::force_sym_f32<0, 1, false, true>", "n": 25000, "grid_workgroups": 2450, "commit": "abc"}]}
+    e, st = b.pmc_lookup(book, k, 262144, 8187)
+    assert st == "match" and e["valu_busy"] == 0.95
+    e, st = b.pmc_lookup(book, k, 262144, 5629)                               # same kernel, another plan (--chunks-per-item)
+    assert e is None and st.startswith("stale") and "5629 items" in st
+    e, st = b.pmc_lookup(book, "nbk::force_sym_f32<0, 1, true, false>", 262144, 8187)     # --general-mass: another instantiation
+    assert e is None and st.startswith("stale") and "abc" in st
+    assert b.pmc_lookup(book, k, 65536, 3428) == (None, "none")
+    assert b.pmc_lookup({}, k, 262144, 8187) == (None, "none") and b.pmc_lookup(book, None, 262144, 8187)[0] is None
+    # the single-record file of rounds 1-3 (no entries list) is never matched: it names no full instantiation and no commit
+    assert b.pmc_lookup({"kernel": "nbk::force_sym_f32<0, 0, true>", "n": 262144}, k, 262144, 8187) == (None, "none")

@@ -126,6 +126,17 @@ def test_mass_mixture_scaled_kernel_vs_fp64_and_fallbacks(nbo):
     print("mass mixture, max error / force scale: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert errs["default"] < 2e-5 and errs["one-sided"] < 2e-5, errs
     assert errs["scaled"] < 2e-4 and errs["one-sided scaled"] < 2e-4, errs
+    # the mass-scaled form's SELF TERM (include/nbody.h): a body's pair with itself leaves up to 6e-8 |x| m / eps^3 behind, so the
+    # net force sum_i m_i a_i — zero to rounding with the default kernels (antisymmetric pair terms) — is conserved to that level only
+    m = ic["mass"].astype(np.float64)
+    net = {}
+    for name, kw in (("default", {}), ("scaled", dict(mass_scaling=True))):
+        with nb.Simulation(ic, eps=EPS, **kw) as sim:
+            acc = sim.accelerations().astype(np.float64)
+        net[name] = float(np.linalg.norm((m[:, None] * acc).sum(0)) / np.abs(m[:, None] * acc).sum())
+    bound = float(np.sum(m * 6e-8 * np.linalg.norm(ic["pos"].astype(np.float64), axis=1) * m / EPS ** 3) / np.abs(m[:, None] * acc).sum())
+    print(f"net force / sum |m a|: default {net['default']:.2e}, mass-scaled {net['scaled']:.2e} (self-term bound {bound:.2e})")
+    assert net["default"] < 1e-6 and net["scaled"] < max(1e-6, 2.0 * bound), (net, bound)
     tracer = ic.copy()
     tracer["mass"][123] = 0.0                                  # a massless tracer: sigma = m^(-1/2) does not exist
     with nb.Simulation(tracer, eps=EPS, mass_scaling=True) as sim:
