@@ -472,6 +472,11 @@ static int copy_d2h(nb_sim *s, void *dst, const void *src, size_t bytes, hipStre
             HIPCHK(hipMemcpyAsync((char *)stage + off, (const char *)src + off, len, hipMemcpyDeviceToHost, st));
             HIPCHK(hipEventRecord(s->ev_bounce[k], st));
         }
+        // Copy-out on the calling thread, piece k as soon as its DMA has landed (the copy of piece k overlaps the DMA of piece k + 1).
+        // Round 4 tried helper threads for pieces 1 .. 3 (9.68 -> 9.31 ms per frame of the reference caller's loop at N = 262 144):
+        // dropped — after threads that had touched HIP exited, RCCL's ncclCommInitAll failed in the same process ("unhandled cuda
+        // error", tests/test_host_gpu.py, twice in two runs); a caller that wants the 0.35 ms keeps `bodies` in nb_host_alloc memory
+        // (direct DMA) or uses the pipelined snapshot.
         k = 0;
         for (size_t off = 0; off < bytes; off += piece, ++k) {
             const size_t len = bytes - off < piece ? bytes - off : piece;

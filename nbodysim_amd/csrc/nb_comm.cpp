@@ -70,7 +70,22 @@ int load_rccl()
         lib = dlopen(g_transport_path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) return nb_fail(NB_ENODEVICE, "nb_comm: the transport named with nb_debug_comm_transport is not loadable (%s)", dlerror());
     } else {
-        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that sits on the SAME HIP / HSA runtime as this library: a process can hold two ROCm stacks (PyTorch bundles
+        // its own libamdhip64 / libhsa-runtime64 / librccl under torch/lib), and a bare dlopen("librccl.so.1") returns whichever
+        // copy was loaded first — if that is the copy of the OTHER stack, its runtime has never seen a device
+        // ("no ROCm-capable device is detected" out of ncclCommInitAll; found when `import torch` came after this library's
+        // first HIP call).  So: look next to the libamdhip64 this library's HIP calls resolve to, then fall back to the SONAME.
+        Dl_info hip_at;
+        if (dladdr((const void *)&hipGetDeviceCount, &hip_at) && hip_at.dli_fname) {
+            std::string dir(hip_at.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                lib = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (!lib) lib = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     }
     if (!lib) return nb_fail(NB_ENODEVICE, "nb_comm: RCCL is not loadable (%s); the C-level exchange has no other transport", dlerror());

@@ -5,6 +5,8 @@ import os
 import re
 import subprocess
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -234,8 +236,17 @@ def test_handles_and_communicators_release_their_device_memory():
     """Create / use / destroy a few dozen handles (plain, mass-scaled, single-rank sharded + nb_comm, snapshot, momentum,
     energy): the free device memory comes back (a leak of a slab, a sigma array, partial-sum buffers, streams or events
     would show as a steady loss)."""
-    import torch
     from nbodysim_amd.comm import Comm
+    # free device memory through the HIP runtime the LIBRARY uses (already loaded: the same copy resolves here).  Not through
+    # torch: PyTorch bundles a second ROCm stack, and when it is imported after this library's first HIP call its runtime
+    # finds no device ("No HIP GPUs are available") — the order in which this file's tests run alone.
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
     n = 65536
     ic = nb.plummer_2d(n, 1)
     gen = ic.copy()
@@ -256,10 +267,8 @@ def test_handles_and_communicators_release_their_device_memory():
             L.check("nb_sync", nb.load().nb_sync(s._h, pb.array.ctypes.data))
 
     cycle()                                               # first use: runtime pools, RCCL, code objects
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    free0 = free_bytes()
     for _ in range(8):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = free_bytes()
     assert free0 - free1 < 64 << 20, f"device memory lost over 8 cycles: {(free0 - free1) / 2**20:.1f} MiB"
