@@ -252,7 +252,10 @@ static bool sym_eligible(const nb_sim *s)
     if (s->p.sum_order != NB_SUM_TILED || needs_guard(s)) return false;
     if (s->fp64 && s->p.rsqrt_mode != NB_RSQRT_EXACT) return false;
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
-    if (s->n < 8 * (size_t)SYM_SB) return false;
+    // smallest system worth the symmetric scheme: 16 384 bodies with the classic tiles (rounds 1-3); with the wave-split tiles it
+    // overtakes the one-sided kernel from ~9 000 bodies on (-12 % at 10 000, -13 % at 12 288, -19 % at 14 336; +4 ... +7 % at 8 192:
+    // tools/small_n_check.py, profiles/r04_small_n_check.log)
+    if (s->n < (sym_tile_of(s->p, s->n) == SYM_SB_WS ? (size_t)9216 : 8 * (size_t)SYM_SB)) return false;
     const uint32_t world = s->p.shard_world > 1 ? (uint32_t)s->p.shard_world : 1u;
     // Travelling partials: one element per (tile, later particle) pair the handle evaluates — tiles x n / 2 for a
     // whole system (1 GiB at N = 524 288 fp32, 2 GiB at 1 048 576, 32 GiB at 4 194 304), 1/world of that for a rank.
@@ -334,7 +337,7 @@ static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t worl
     t.sb = sym_tile_of(p, n);
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
-        for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k];
+        { for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k]; t.tail_given = true; }
     return t;
 }
 

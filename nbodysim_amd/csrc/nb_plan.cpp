@@ -91,7 +91,11 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     uint32_t L = tune.forced_L;
     if (!L) {
         const uint32_t fill = (uint32_t)((units + target - 1) / target);
-        const uint32_t grain = (uint32_t)(std::sqrt((double)units) * 256.0 / (20.0 * (double)cus) + 0.5);
+        // (round 4, wave-split kernels and chunk pairs in place: items ~ 16 sqrt(units) with an earlier tail measures 1-2 % faster at
+        // N = 25 000 ... 65 536 than the 20 sqrt(units) of round 1; profiles/r04_tail_sweep.log)
+        // The ranks of a sharded run keep round 1-3's grain and tail: their optimum (9 chunks per item at 8 ranks) was measured
+        // with them (profiles/r02_shard_L_sweep.log).
+        const uint32_t grain = (uint32_t)(std::sqrt((double)units) * 256.0 / ((world > 1 ? 20.0 : 16.0) * (double)cus) + 0.5);
         L = fill > grain ? fill : grain;
     }
     if (L < 1) L = 1;
@@ -163,13 +167,23 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         auto guided = [&](std::vector<SymItem> &list, std::vector<uint32_t> &rows_of) {
             uint64_t total = 0, done = 0;
             for (const auto &it : list) total += it.cnt;
+            // A launch of few rounds (items per resident workgroup slot, ~4 slots per CU) ends with a larger share of its work in the
+            // last, partly filled round: the finer items start earlier there (0.65 / 0.85 / 0.95 below 6 rounds instead of 0.85 / 0.94 /
+            // 0.98: -9 % at N = 16 384 (with tail pieces of fewer chunks than waves), -1 % at 65 536, +-1 % elsewhere, the headline plan
+            // — 8 187 items, 8 rounds — unchanged; profiles/r04_tail_sweep.log, r04_defaults_check.log).  Explicit
+            // thresholds (nb_params.sym_tail) are taken as given.
+            double at[3] = {tune.tail_at[0], tune.tail_at[1], tune.tail_at[2]};
+            if (!tune.tail_given && world == 1 && (double)list.size() < 6.0 * 4.0 * (double)cus) { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }
             std::vector<SymItem> out;
             out.reserve(list.size() * 2);
             for (const auto &it : list) {
                 const double f = total ? (double)done / (double)total : 0.0;
-                const uint32_t div = f < tune.tail_at[0] ? 1u : f < tune.tail_at[1] ? 2u : f < tune.tail_at[2] ? 4u : 8u;
+                const uint32_t div = f < at[0] ? 1u : f < at[1] ? 2u : f < at[2] ? 4u : 8u;
                 uint32_t piece = (L + div - 1) / div;
-                piece = ((piece + unit - 1) / unit) * unit;
+                // tail pieces of a wave-split plan may hold fewer chunks than waves (idle waves cost nothing while the launch drains;
+                // balance is what the tail is for): only the evenness chunk pairs need is kept
+                const uint32_t tail_unit = tune.even_chunks ? 2u : 1u;
+                piece = ((piece + tail_unit - 1) / tail_unit) * tail_unit;
                 done += it.cnt;
                 if (div == 1 || it.cnt <= piece) { out.push_back(it); continue; }
                 --rows_of[it.tile];

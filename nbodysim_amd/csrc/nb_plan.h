@@ -50,6 +50,7 @@ struct SymTuning {
                                   // cut into multiples of 4 chunks (one per wave; 8 with chunk pairs) — see quantum()
     uint32_t quantum() const { return (sb == SYM_SB_WS ? 4u : 1u) * (even_chunks ? 2u : 1u); }
     double tail_at[3] = {0.85, 0.94, 0.98};
+    bool tail_given = false;      // tail_at was set by the caller (nb_params.sym_tail): no size-dependent adjustment
 };
 
 struct SymPlan {

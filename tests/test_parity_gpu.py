@@ -235,7 +235,7 @@ def test_uniform_mass_fast_path_matches_general_path(nbo):
         assert "uniform_mass=0" in sim.describe()
 
 
-@pytest.mark.parametrize("n", [16384, 20000, 70001])
+@pytest.mark.parametrize("n", [9300, 12288, 16384, 20000, 70001])
 @pytest.mark.parametrize("masses", ["uniform", "individual"])
 @pytest.mark.parametrize("rsqrt", ["exact", "quake"])
 @pytest.mark.parametrize("pairs,chunks", [(-1, 0), (1, 0), (1, 3)])
