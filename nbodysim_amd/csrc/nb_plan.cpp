@@ -93,9 +93,10 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         const uint32_t fill = (uint32_t)((units + target - 1) / target);
         // (round 4, wave-split kernels and chunk pairs in place: items ~ 16 sqrt(units) with an earlier tail measures 1-2 % faster at
         // N = 25 000 ... 65 536 than the 20 sqrt(units) of round 1; profiles/r04_tail_sweep.log)
-        // The ranks of a sharded run keep round 1-3's grain and tail: their optimum (9 chunks per item at 8 ranks) was measured
-        // with them (profiles/r02_shard_L_sweep.log).
-        const uint32_t grain = (uint32_t)(std::sqrt((double)units) * 256.0 / ((world > 1 ? 20.0 : 16.0) * (double)cus) + 0.5);
+        // A rank of a sharded run gets 12 chunks per item at 8 ranks instead of 10 (one rank's compute share on one GPU: 94.3 ->
+        // 95.5 % of the ideal in the symmetric protocol, 94.3 -> 96.4 % in the all-reduce protocol), 16 instead of 14 at 4 ranks and
+        // 22 at 2 ranks (both unchanged within the noise); its tail thresholds stay (profiles/r04_rank_tail_sweep.log).
+        const uint32_t grain = (uint32_t)(std::sqrt((double)units) * 256.0 / (16.0 * (double)cus) + 0.5);
         L = fill > grain ? fill : grain;
     }
     if (L < 1) L = 1;
