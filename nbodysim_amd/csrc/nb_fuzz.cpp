@@ -229,6 +229,36 @@ static void fuzz_schedule(int cases, std::mt19937 &rng)
     }
 }
 
+// The RCCL id file of a one-process-per-GPU launch (nb_comm_id_publish / _await, nb_host.c): round trip, a stale file of
+// another launch, truncated and damaged files, over-long paths — under the sanitizers.
+static void fuzz_idfile(const std::string &dir, std::mt19937 &rng)
+{
+    const std::string path = dir + "/nb_fuzz_" + std::to_string((unsigned long)getpid()) + ".id";
+    unsigned char id[NB_COMM_ID_BYTES], got[NB_COMM_ID_BYTES];
+    for (int round = 0; round < 20; ++round) {
+        for (unsigned char &b : id) b = (unsigned char)rng();
+        const uint64_t nonce = ((uint64_t)rng() << 32) | rng();
+        REQUIRE(nb_comm_id_publish(path.c_str(), nonce, id) == NB_OK, "publish: %s", nb_last_error());
+        REQUIRE(nb_comm_id_await(path.c_str(), nonce, got, 200) == NB_OK && memcmp(id, got, sizeof id) == 0, "await: %s", nb_last_error());
+        REQUIRE(nb_comm_id_await(path.c_str(), nonce + 1, got, 30) == NB_EIO, "a file of another launch was taken for this one");
+        // damage: truncate to a random length / flip a byte of the magic: never an id
+        std::vector<unsigned char> raw(8 + 8 + NB_COMM_ID_BYTES);
+        FILE *f = std::fopen(path.c_str(), "rb");
+        REQUIRE(f && std::fread(raw.data(), 1, raw.size(), f) == raw.size(), "id file has the documented size");
+        std::fclose(f);
+        const size_t cut = rng() % raw.size();
+        write_raw(path, raw.data(), cut);
+        REQUIRE(nb_comm_id_await(path.c_str(), nonce, got, 30) == NB_EIO, "truncated id file accepted (%zu bytes)", cut);
+        raw[rng() % 8] ^= 0x40;
+        write_raw(path, raw.data(), raw.size());
+        REQUIRE(nb_comm_id_await(path.c_str(), nonce, got, 30) == NB_EIO, "id file with a damaged magic accepted");
+    }
+    unlink(path.c_str());
+    const std::string longpath(5000, 'x');
+    REQUIRE(nb_comm_id_publish((dir + "/" + longpath).c_str(), 1, id) != NB_OK, "over-long path accepted");
+    REQUIRE(nb_comm_id_publish(nullptr, 1, id) == NB_EINVAL && nb_comm_id_await(path.c_str(), 1, nullptr, 10) == NB_EINVAL, "NULL arguments");
+}
+
 int main(int argc, char **argv)
 {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 300;
@@ -238,6 +268,7 @@ int main(int argc, char **argv)
     fuzz_planner(cases, rng);
     fuzz_host(dir, rng);
     fuzz_schedule(cases, rng);
+    fuzz_idfile(dir, rng);
     std::printf("OK planner_cases=%d seed=%u\n", cases, seed);
     return 0;
 }
