@@ -123,6 +123,14 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          SLOWER on MI355X at every size measured (+3 % at N = 262 144, +60 ... +240 % below 65 536: every
                                          in-launch hand-off costs 15-25 us of fence / atomic / poll latency, the two launch boundaries and the
                                          dedicated gather launch it replaces cost ~21 us per step in all) */
+       NB_FLAG_ONE_LAUNCH_STEP = 128, /* EXPERIMENTAL, off by default: whole-system fp32 2-D kick-drift handles run a step as ONE launch (sym_step_f32:
+                                         the gather + kick + drift workgroups follow the force items in the same grid and wait, tile by tile, for
+                                         the items' arrivals; same sums, bit-identical results).  -0.5 ... -1.4 % per step at N = 25 000 ... 65 536,
+                                         +1.5 % at 16 384, within the noise from 131 072 up (profiles/r04_one_launch_ab.log): what follows the last
+                                         force item — arrival, poll, acquire, gather — is as long as the launch boundary + gather launch it replaces.
+                                         Not the default because its progress argument rests on workgroups being dispatched in index order, which
+                                         HIP does not promise (a wait that does not end sets an error word within 4 s; the handle is then refused);
+                                         DESIGN.md 4.8 */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange

@@ -120,6 +120,10 @@ struct nb_sim {
     u64_t pipe_epoch = 0, pipe_tickets = 0;    // steps / tickets the pipeline has completed so far (its counters are monotonic)
     uint32_t pipe_grid = 0;                    // resident workgroups of the variant this handle launches
     u64_t *pipe_dbg = nullptr;                 // nb_debug_pipeline_watch: page-locked host words, one per workgroup
+    // one launch per step (sym_step_f32): the gather + kick + drift ride in the drain of the force launch
+    bool fused = false;                        // the handle steps that way (decided in plan_sym; opt-in NB_FLAG_ONE_LAUNCH_STEP)
+    uint32_t *step_done = nullptr;             // device: per-tile arrivals, monotonic modulo 2^32
+    uint32_t step_epoch = 0;                   // fused launches so far (modulo 2^32, like the counters)
     hipStream_t dbg_stream = nullptr;
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
@@ -546,7 +550,11 @@ static int plan_sym(nb_sim *s)
     // that touch tile g (their stationary tile, or a tile their travelling chunks lie in); an item's tiles must fit the
     // kernel's 32-bit "I was last" mask (1 + 31 tiles: any plan the planner sizes itself, not every forced one).
     s->pipe = false;
-    if (s->sym && !s->fp64 && !s->dims3 && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT && (s->p.flags & NB_FLAG_PIPELINE)) {
+    s->fused = false;
+    const bool whole_f32 = s->sym && !split && !s->fp64 && !s->dims3 && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT;
+    const bool want_pipe = whole_f32 && (s->p.flags & NB_FLAG_PIPELINE);
+    const bool want_fused = whole_f32 && !want_pipe && (s->p.flags & NB_FLAG_ONE_LAUNCH_STEP);
+    if (want_pipe || want_fused) {
         const uint32_t shift = pl.sb == SYM_SB_WS ? 9u : 11u;
         std::vector<uint32_t> expected(tiles, 0u);
         uint32_t span = 0;
@@ -558,7 +566,17 @@ static int plan_sym(nb_sim *s)
             for (uint32_t g = t_lo; g <= t_hi; ++g) ++expected[g];
             if (t_hi - t_lo + 1u > span) span = t_hi - t_lo + 1u;
         }
-        if (span <= 31u) {
+        HIPCHK(hipMalloc((void **)&s->pipe_expected_dev, tiles * sizeof(uint32_t)));
+        if ((rc = copy_h2d(s, s->pipe_expected_dev, expected.data(), tiles * sizeof(uint32_t)))) return rc;
+        HIPCHK(hipHostMalloc((void **)&s->pipe_err, sizeof(int), hipHostMallocDefault));
+        *s->pipe_err = 0;
+        if (want_fused) {
+            // One launch per step (sym_step_f32): per-tile arrival counters, zero at epoch 0.
+            HIPCHK(hipMalloc((void **)&s->step_done, (size_t)tiles * STEP_CTR_STRIDE * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(s->step_done, 0, (size_t)tiles * STEP_CTR_STRIDE * sizeof(uint32_t), s->stream));
+            s->step_epoch = 0;
+            s->fused = true;
+        } else if (span <= 31u) {
             // PIPE ORDER.  Tile-major order (tile I against every later chunk, I ascending) is what one launch per step wants, but
             // in a pipeline the first items of the next step — tile 0 against EVERY tile — would need every tile of this step
             // finished.  Tickets are therefore drawn along the ANTI-DIAGONALS of the (tile, chunk-tile) triangle, s = I + t
@@ -571,13 +589,9 @@ static int plan_sym(nb_sim *s)
             std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
             HIPCHK(hipMalloc((void **)&s->pipe_order_dev, order.size() * sizeof(uint32_t)));
             if ((rc = copy_h2d(s, s->pipe_order_dev, order.data(), order.size() * sizeof(uint32_t)))) return rc;
-            const size_t words = 1 + 5 * (size_t)tiles;
+            const size_t words = (1 + 5 * (size_t)tiles) * PIPE_CTR_STRIDE;     // [head | done | summable | claim | fin | ready], one 128-byte line per counter
             HIPCHK(hipMalloc((void **)&s->pipe_ctr, words * sizeof(u64_t)));
             HIPCHK(hipMemsetAsync(s->pipe_ctr, 0, words * sizeof(u64_t), s->stream));
-            HIPCHK(hipMalloc((void **)&s->pipe_expected_dev, tiles * sizeof(uint32_t)));
-            if ((rc = copy_h2d(s, s->pipe_expected_dev, expected.data(), tiles * sizeof(uint32_t)))) return rc;
-            HIPCHK(hipHostMalloc((void **)&s->pipe_err, sizeof(int), hipHostMallocDefault));
-            *s->pipe_err = 0;
             s->pipe = true;
         }
     }
@@ -616,7 +630,7 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
-    (void)hipFree(s->pipe_ctr); (void)hipFree(s->pipe_expected_dev); (void)hipFree(s->pipe_order_dev);
+    (void)hipFree(s->pipe_ctr); (void)hipFree(s->pipe_expected_dev); (void)hipFree(s->pipe_order_dev); (void)hipFree(s->step_done);
     if (s->pipe_err) (void)hipHostFree(s->pipe_err);
     if (s->pipe_dbg) (void)hipHostFree(s->pipe_dbg);
     if (s->dbg_stream) (void)hipStreamDestroy(s->dbg_stream);
@@ -713,7 +727,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_PIPELINE)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_PIPELINE | NB_FLAG_ONE_LAUNCH_STEP)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
@@ -1051,6 +1065,50 @@ static int launch_sym_gather_late(nb_sim *s, double dt)
     return NB_OK;
 }
 
+// One step of a whole-system fp32 2-D handle as ONE launch (sym_step_f32): the force items, then — in the slots the last
+// items leave free — the gather workgroups, each waiting for its tile's arrivals.  Same items, slabs and sums as
+// launch_sym_items + launch_sym_gather(fuse_step): bit-identical results.
+static int launch_sym_step(nb_sim *s, float dt)
+{
+    if (s->pipe_failed) return nb_fail(NB_ESTATE, "nb_step: an earlier launch gave up (a device-side wait timed out); the handle cannot continue");
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.pos_cur = (const float2 *)s->pos[s->cur]; a.pos_next = (float2 *)s->pos[s->cur ^ 1];
+    a.mass = (const float *)s->mass; a.sigma = s->sigma;
+    a.items = s->sym_items_dev;
+    a.slab_s = (float2 *)s->sym_slab_s; a.slab_r = (float2 *)s->sym_slab_r;
+    a.row_lo = s->sym_rowbase_dev; a.row_hi = s->sym_rowbase_dev + s->sym_tiles;      // no late rows in a whole-system plan
+    a.cov_begin = s->sym_cov_begin_dev; a.cov = s->sym_cov_dev;
+    a.expected = s->pipe_expected_dev; a.done = s->step_done; a.err = s->pipe_err;
+    a.vel = (float2 *)s->vel; a.acc = (float2 *)s->acc;
+    a.n = (uint32_t)s->n; a.n_items = s->sym_items; a.sb_shift = s->sym_sb_shift;
+    a.epoch = ++s->step_epoch;
+    a.eps2 = s->p.eps * s->p.eps; a.um_mass = s->uniform_mass ? s->um_mass : 1.0f; a.dt = dt; a.extras = s->p.extras;
+    const uint32_t grid = s->sym_items + (a.n + (uint32_t)GATHER_P - 1u) / (uint32_t)GATHER_P;
+    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE, ws = s->sym_sb == SYM_SB_WS;
+    const bool pairs = s->sym_pairs && !s->mass_scaled;
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+#define NB_STEP_GO(RQ, MMODE, PR)                                                                                   \
+    do {                                                                                                             \
+        if (ws) sym_step_f32<RQ, MMODE, PR, true><<<grid, BLOCK, 0, s->stream>>>(a);                                 \
+        else    sym_step_f32<RQ, MMODE, PR, false><<<grid, BLOCK, 0, s->stream>>>(a);                                \
+    } while (0)
+    if (s->uniform_mass) {
+        if (quake) { if (pairs) NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, true); else NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, false); }
+        else       { if (pairs) NB_STEP_GO(RSQ_EXACT, MM_UNIFORM, true); else NB_STEP_GO(RSQ_EXACT, MM_UNIFORM, false); }
+    } else if (s->mass_scaled) {
+        NB_STEP_GO(RSQ_EXACT, MM_SCALED, false);
+    } else {
+        if (quake) { if (pairs) NB_STEP_GO(RSQ_QUAKE, MM_GENERAL, true); else NB_STEP_GO(RSQ_QUAKE, MM_GENERAL, false); }
+        else       { if (pairs) NB_STEP_GO(RSQ_EXACT, MM_GENERAL, true); else NB_STEP_GO(RSQ_EXACT, MM_GENERAL, false); }
+    }
+#undef NB_STEP_GO
+    HIPCHK(hipGetLastError());
+    if (s->prof && prof_end(s, pr)) return NB_EHIP;
+    return NB_OK;
+}
+
 // Whole-system symmetric force (+ optionally the kick/drift).
 static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
 {
@@ -1295,8 +1353,9 @@ extern "C" int nb_step_finish(nb_sim *s)
         return NB_OK;
     }
     if (s->sym && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT) {
-        // whole system, symmetric kernel: the gather applies the kick and the drift itself
-        if ((rc = launch_force_sym(s, true, (double)s->pending_dt))) return rc;
+        // whole system, symmetric kernel: the gather applies the kick and the drift itself — inside the force launch where the
+        // handle can (sym_step_f32), as a second launch otherwise
+        if ((rc = s->fused ? launch_sym_step(s, s->pending_dt) : launch_force_sym(s, true, (double)s->pending_dt))) return rc;
         s->cur ^= 1;
         s->frame += 1;
         s->acc_valid = false;
@@ -1337,8 +1396,9 @@ static int launch_pipeline(nb_sim *s, float dt, int nsteps)
     a.cov_begin = s->sym_cov_begin_dev; a.cov = s->sym_cov_dev;
     a.expected = s->pipe_expected_dev;
     a.vel = (float2 *)s->vel; a.acc = (float2 *)s->acc;
-    a.head = s->pipe_ctr; a.done = s->pipe_ctr + 1; a.summable = a.done + s->sym_tiles; a.claim = a.summable + s->sym_tiles;
-    a.fin = a.claim + s->sym_tiles; a.ready = a.fin + s->sym_tiles;
+    const size_t per = (size_t)s->sym_tiles * PIPE_CTR_STRIDE;
+    a.head = s->pipe_ctr; a.done = s->pipe_ctr + PIPE_CTR_STRIDE; a.summable = a.done + per; a.claim = a.summable + per;
+    a.fin = a.claim + per; a.ready = a.fin + per;
     a.err = s->pipe_err;
     a.dbg = s->pipe_dbg;
     a.n = (uint32_t)s->n; a.n_items = s->sym_items; a.tiles = s->sym_tiles; a.sb_shift = s->sym_sb_shift;
@@ -1391,7 +1451,7 @@ static int pipe_check(nb_sim *s)
 {
     if (s->pipe_err && *(volatile int *)s->pipe_err != 0) {
         s->pipe_failed = true;
-        return nb_fail(NB_EHIP, "the step pipeline gave up (code %d: 1 = a device-side wait for a tile did not end within %.0f s, 2 / 3 = a bounded "
+        return nb_fail(NB_EHIP, "a step launch gave up (code %d: 1 = a device-side wait for a tile did not end within %.0f s, 2 / 3 = a bounded "
                                 "loop ran out): this is a bug in the library, not a legal state; the handle's state is undefined",
                        *(volatile int *)s->pipe_err, (double)PIPE_TIMEOUT_TICKS * 1e-8);
     }
@@ -1928,10 +1988,13 @@ extern "C" int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t w
     if (tiles) *tiles = s->sym_tiles;
     if (workgroups && s->pipe_dbg) memcpy(workgroups, s->pipe_dbg, (wg_cap < PIPE_DBG_WORDS ? wg_cap : PIPE_DBG_WORDS) * sizeof(uint64_t));
     if (counters && s->dbg_stream) {
+        // the caller's view is compact ([head | done | summable | claim | fin | ready], tiles words each); on the device every counter has a line of its own
         const size_t words = 1 + 5 * (size_t)s->sym_tiles, k = ctr_cap < words ? ctr_cap : words;
         if (bind(s)) return NB_EHIP;
-        HIPCHK(hipMemcpyAsync(counters, s->pipe_ctr, k * sizeof(uint64_t), hipMemcpyDeviceToHost, s->dbg_stream));
+        std::vector<uint64_t> raw(words * PIPE_CTR_STRIDE);
+        HIPCHK(hipMemcpyAsync(raw.data(), s->pipe_ctr, raw.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s->dbg_stream));
         HIPCHK(hipStreamSynchronize(s->dbg_stream));
+        for (size_t i = 0; i < k; ++i) counters[i] = raw[i * PIPE_CTR_STRIDE];
     }
     return NB_OK;
 }
@@ -1952,13 +2015,13 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d pipeline=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d pipeline=%d one_launch=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
-             (int)(s->sym || s->sym_sharded || s->sym_replicated), (int)s->pipe, s->sym_sb,
+             (int)(s->sym || s->sym_sharded || s->sym_replicated), (int)s->pipe, (int)s->fused, s->sym_sb,
              (int)(s->sym_pairs && !s->mass_scaled && (!s->dims3 || s->uniform_mass || s->p.sym_chunk_pairs > 0)), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;

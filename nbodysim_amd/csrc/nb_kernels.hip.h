@@ -76,21 +76,20 @@ __device__ __forceinline__ void store16(float4 *p, float4 v)
 // ---------------------------------------------------------------------------
 enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
 
+// v, x: the particle's velocity and position, loaded by the caller (sym_gather_block loads them before it sums, so that the
+// two loads are not one more memory latency at the end of a latency-bound kernel); unused unless flags has INTEG_KICK.
 template <typename real, bool STRICT, bool WT = false>
 __device__ __forceinline__
-void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
-                    const typename vec2_of<real>::type *__restrict__ pos_cur,
-                    typename vec2_of<real>::type *__restrict__ pos_next,
-                    typename vec2_of<real>::type *__restrict__ vel,
-                    typename vec2_of<real>::type *__restrict__ acc,
-                    uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
+void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::type v, const typename vec2_of<real>::type x, uint32_t li,
+                       typename vec2_of<real>::type *__restrict__ pos_next,
+                       typename vec2_of<real>::type *__restrict__ vel,
+                       typename vec2_of<real>::type *__restrict__ acc,
+                       uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
 {
     typedef typename vec2_of<real>::type real2;
     static_assert(!WT || sizeof(real) == 4, "write-through stores: the fp32 pipeline only");
     if constexpr (WT) store8<true>(&acc[li], a); else acc[li] = a;
     if (!(flags & INTEG_KICK)) return;              // acceleration gather only
-    real2 v = vel[li];
-    const real2 x = pos_cur[i_begin + li];
     if constexpr (STRICT) {
 #pragma clang fp contract(off)
         v.x += a.x * dt_kick;                       // Simulation.hpp:130-131
@@ -137,6 +136,21 @@ void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
         }
         if constexpr (WT) store8<true>(&pos_next[i_begin + li], xn); else pos_next[i_begin + li] = xn;
     }
+}
+
+template <typename real, bool STRICT, bool WT = false>
+__device__ __forceinline__
+void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
+                    const typename vec2_of<real>::type *__restrict__ pos_cur,
+                    typename vec2_of<real>::type *__restrict__ pos_next,
+                    typename vec2_of<real>::type *__restrict__ vel,
+                    typename vec2_of<real>::type *__restrict__ acc,
+                    uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
+{
+    typename vec2_of<real>::type v, x;
+    v.x = v.y = x.x = x.y = 0;
+    if (flags & INTEG_KICK) { v = vel[li]; x = pos_cur[i_begin + li]; }
+    kick_drift_loaded<real, STRICT, WT>(a, v, x, li, pos_next, vel, acc, i_begin, dt_kick, dt_drift, extras, flags);
 }
 
 // ---------------------------------------------------------------------------
@@ -853,6 +867,10 @@ void sym_gather_block(uint32_t blk,
     const uint32_t p = threadIdx.x % GATHER_T, q = threadIdx.x / GATHER_T;
     const uint32_t li = blk * GATHER_P + 2u * p, k = k0 + li;
     real2 a0, a1; a0.x = a0.y = a1.x = a1.y = 0;
+    // thread f < GATHER_P finishes particle f of the workgroup: its velocity and position are fetched now, beside the sums
+    const uint32_t f = threadIdx.x, lf = blk * GATHER_P + f;
+    real2 vf, xf; vf.x = vf.y = xf.x = xf.y = 0;
+    if constexpr (FUSE) { if (f < (uint32_t)GATHER_P && lf < kn && (flags & INTEG_KICK)) { vf = vel[lf]; xf = pos_cur[k0 + lf]; } }
     if (li < kn) {
         const uint32_t g = k >> sb_shift, loc = k & ((1u << sb_shift) - 1u);
         const uint32_t r0 = row_lo[g], r1 = row_hi[g];
@@ -862,27 +880,43 @@ void sym_gather_block(uint32_t blk,
             load_pair(slab_s + ((size_t)r << sb_shift) + loc, b0, b1);   // rows are whole tiles: loc + 1 is inside
             a0.x += b0.x; a0.y += b0.y; a1.x += b1.x; a1.y += b1.y;
         }
+        // Coverage entries, four at a time: the four descriptors, then the four partial pairs they point at, are loaded as
+        // independent batches (entry by entry the loop was a chain of two dependent memory latencies per entry: the last tiles
+        // of a plan — the longest lists — set the duration of the whole gather); the adds keep their order.  An entry that does
+        // not cover k reads element 0 of the slab (present whenever a list is non-empty) and adds nothing.
         const uint32_t c1 = cov_begin[g + 1];
-        for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
-            const SymCov cv = cov[i];
-            if (k < cv.lo || k >= cv.hi) continue;
-            real2 b0, b1;
-            load_pair(slab_r + (cv.base + (int64_t)k), b0, b1);          // the element after an odd-length segment is padding
-            a0.x += b0.x; a0.y += b0.y;
-            if (k + 1 < cv.hi) { a1.x += b1.x; a1.y += b1.y; }
+        for (uint32_t i = cov_begin[g] + q; i < c1; i += 4u * GATHER_Q) {
+            SymCov cv[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t idx = i + (uint32_t)u * GATHER_Q;
+                in[u] = idx < c1;
+                cv[u] = cov[in[u] ? idx : c1 - 1u];
+            }
+            real2 b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                in[u] = in[u] && k >= cv[u].lo && k < cv[u].hi;
+                load_pair(slab_r + (in[u] ? cv[u].base + (int64_t)k : (int64_t)0), b0[u], b1[u]);   // the element after an odd-length segment is padding
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!in[u]) continue;
+                a0.x += b0[u].x; a0.y += b0[u].y;
+                if (k + 1 < cv[u].hi) { a1.x += b1[u].x; a1.y += b1[u].y; }
+            }
         }
     }
     part[q][2u * p] = a0;
     part[q][2u * p + 1] = a1;
     __syncthreads();
-    // thread t < 64 finishes particle t of the workgroup
-    const uint32_t f = threadIdx.x, lf = blk * GATHER_P + f;
     if (f < (uint32_t)GATHER_P && lf < kn) {
         real2 t = part[0][f];
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][f].x; t.y += part[j][f].y; }
         if (base) { const real2 bb = base[lf]; t.x += bb.x; t.y += bb.y; }
-        if constexpr (FUSE) kick_drift_one<real, false, WT>(t, lf, pos_cur, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
+        if constexpr (FUSE) kick_drift_loaded<real, false, WT>(t, vf, xf, lf, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
         else acc_sum[k0 + lf] = t;
     }
 }
@@ -904,6 +938,102 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 {
     sym_gather_block<real, FUSE>(blockIdx.x, slab_s, slab_r, row_lo, row_hi, cov_begin, cov, n, k0, kn, acc_sum, base, pos_cur, pos_next, vel, acc,
                                  dt_kick, dt_drift, extras, flags, sb_shift);
+}
+
+// ---------------------------------------------------------------------------
+// sym_step_f32 — ONE launch per step: the force items AND the gather + kick + drift of a whole-system handle (round 4).
+//
+// Grid = n_items force workgroups followed by ceil(n / GATHER_P) gather workgroups.  Workgroups are dispatched in index
+// order, so the gather workgroups take the slots the LAST force items leave free: the launch's drain, where CUs stand
+// partly idle anyway.  A gather workgroup sums 64 particles of ONE tile g (sym_gather_block: the same rows in the same
+// order and association as the sym_gather launch it replaces -> bit-identical trajectories) once every force item that
+// contributes to tile g has finished:
+//   done[g]   arrivals at tile g (monotonic over the handle's life, modulo 2^32): a finished item adds one to its
+//             stationary tile and to every tile its travelling chunks lie in; tile g is complete for the handle's
+//             `epoch`-th fused launch when done[g] == expected[g] * epoch.
+// The item list is tile-major (nb_plan.cpp), so tiles complete in ascending order while the launch runs and only the
+// last few tiles' gathers are left when the last item ends: the step costs ONE launch boundary and no gather launch
+// (two boundaries + 8.6 us of gather at N = 25 000, 13 us at 65 536, 48 us at 262 144).
+// Progress: force workgroups never wait; a gather workgroup waits only for force workgroups, all of which precede it
+// in dispatch order (they run or have finished when it starts — and if a device ever dispatched out of order, a
+// waiting gather workgroup holds one slot, never all of a launch's: the undispatched items start as other slots
+// free).  A wait that does not end within STEP_TIMEOUT sets *err and the workgroup leaves: the host reports NB_EHIP
+// and refuses the handle.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): producer =
+// write-through (sc1) stores of the slab bytes -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 agent-scope
+// atomic add; consumer = relaxed agent-scope poll -> lane 0 agent ACQUIRE fence -> barrier -> plain vector loads.
+// The gather's own outputs (x, v, a) are read by the NEXT launch: plain stores.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long STEP_TIMEOUT_TICKS = 400000000ull;      // 4 s of the 100 MHz real-time counter
+
+struct StepArgs {
+    const float2 *pos_cur;
+    float2 *pos_next;
+    const float *mass, *sigma;
+    const SymItem *items;
+    float2 *slab_s, *slab_r;
+    const uint32_t *row_lo, *row_hi, *cov_begin;
+    const SymCov *cov;
+    const uint32_t *expected;        // items touching each tile
+    uint32_t *done;                  // per-tile arrivals (see above)
+    int *err;                        // page-locked host word: != 0 once a wait has been given up
+    float2 *vel, *acc;
+    uint32_t n, n_items, sb_shift, epoch;
+    float eps2, um_mass, dt;
+    int extras;
+};
+constexpr uint32_t STEP_CTR_STRIDE = 32;     // words between two tiles' counters: one 128-byte line each (arrivals and polls of different tiles do not queue behind each other)
+
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
+__global__ __launch_bounds__(BLOCK, (PAIRS ? 3 : 4))
+void sym_step_f32(const StepArgs a)
+{
+    const uint32_t t = threadIdx.x;
+    if (blockIdx.x < a.n_items) {
+        const SymItem it = a.items[blockIdx.x];
+        force_sym_f32_body<RSQ, MM, PAIRS, WS, true>(a.pos_cur, a.mass, a.sigma, it, a.slab_s, a.slab_r, a.n, a.eps2, a.um_mass);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through slab stores have left
+        __syncthreads();                                     // ... every wave's
+        if (t == 0) {
+            __hip_atomic_fetch_add(a.done + (size_t)it.tile * STEP_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!it.diag) {
+                const uint32_t lastp = min((it.c0 + it.cnt) * SYM_CH, a.n) - 1u;
+                for (uint32_t g = (it.c0 * SYM_CH) >> a.sb_shift; g <= lastp >> a.sb_shift; ++g)
+                    __hip_atomic_fetch_add(a.done + (size_t)g * STEP_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // ---- gather workgroup: 64 particles of tile g
+    __shared__ uint32_t sh_ok;
+    const uint32_t blk = blockIdx.x - a.n_items;
+    if (t == 0) {
+        const uint32_t g = (blk * (uint32_t)GATHER_P) >> a.sb_shift;
+        const uint32_t want = a.expected[g] * a.epoch;       // modulo 2^32, like the counter
+        uint32_t ok = 1u;
+        const uint32_t *ctr = a.done + (size_t)g * STEP_CTR_STRIDE;
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (uint32_t spins = 1;; ++spins) {
+                __builtin_amdgcn_s_sleep(16);                // ~0.5 us between polls (polling cost, MI355X_MICROARCH.md)
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) break;
+                if ((spins & 63u) != 0u) continue;           // the give-up word and the clock: every 64th poll
+                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { ok = 0u; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > STEP_TIMEOUT_TICKS) {
+                    __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = 0u;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the slabs were in memory before the counter said so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh_ok = ok;
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)sh_ok) == 0) return;
+    sym_gather_block<float, true, false>(blk, a.slab_s, a.slab_r, a.row_lo, a.row_hi, a.cov_begin, a.cov, a.n, 0u, a.n, nullptr, nullptr,
+                                         a.pos_cur, a.pos_next, a.vel, a.acc, a.dt, a.dt, a.extras, INTEG_KICK | INTEG_DRIFT, a.sb_shift);
 }
 
 // ---------------------------------------------------------------------------
@@ -944,6 +1074,9 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 typedef unsigned long long u64_t;
 constexpr u64_t PIPE_TIMEOUT_TICKS = 400000000ull;       // 4 s of the 100 MHz real-time counter
 enum { PIPE_GO = 0, PIPE_HELP = 1, PIPE_FAIL = 2 };
+
+constexpr uint32_t PIPE_CTR_STRIDE = 16;     // u64 words between two counters: every counter of every tile on a 128-byte line of its own
+#define PIPE_AT(base, g) ((base) + (size_t)(g) * PIPE_CTR_STRIDE)
 
 struct PipeArgs {
     const float2 *pos[2];            // replica read by even / odd local steps is pos[(cur0 + step) & 1]
@@ -997,13 +1130,13 @@ __device__ __forceinline__ void pipe_help_tile(const PipeArgs &a, uint32_t g, u6
     for (;;) {
         if (t == 0) {
             if (prev != 0xffffffffu) {
-                const u64_t f = __hip_atomic_fetch_add(a.fin + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (f + 1 == last) __hip_atomic_store(a.ready + g, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64_t f = __hip_atomic_fetch_add(PIPE_AT(a.fin, g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f + 1 == last) __hip_atomic_store(PIPE_AT(a.ready, g), j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            u64_t c = pipe_load(a.claim + g);
+            u64_t c = pipe_load(PIPE_AT(a.claim, g));
             uint32_t piece = 0xffffffffu;
             for (uint32_t tries = 0; c >= first && c < last; ++tries) {
-                if (__hip_atomic_compare_exchange_strong(a.claim + g, &c, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (__hip_atomic_compare_exchange_strong(PIPE_AT(a.claim, g), &c, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     piece = (uint32_t)(c - first);
                     break;
                 }
@@ -1038,11 +1171,11 @@ __device__ __forceinline__ bool pipe_wait_tile(const PipeArgs &a, uint32_t g, u6
             if (rounds > 100000u) {                         // helping that never gets anywhere: a bug; every loop of this kernel is bounded
                 __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 st = PIPE_FAIL;
-            } else if (pipe_load(a.ready + g) < k) {
+            } else if (pipe_load(PIPE_AT(a.ready, g)) < k) {
                 const u64_t t0 = __builtin_amdgcn_s_memrealtime();
                 for (uint32_t spins = 1;; ++spins) {
-                    if (pipe_load(a.ready + g) >= k) { st = PIPE_GO; break; }
-                    if (pipe_load(a.summable + g) >= k && pipe_load(a.claim + g) < ((1ull << a.sb_shift) / (u64_t)GATHER_P) * k) { st = PIPE_HELP; break; }
+                    if (pipe_load(PIPE_AT(a.ready, g)) >= k) { st = PIPE_GO; break; }
+                    if (pipe_load(PIPE_AT(a.summable, g)) >= k && pipe_load(PIPE_AT(a.claim, g)) < ((1ull << a.sb_shift) / (u64_t)GATHER_P) * k) { st = PIPE_HELP; break; }
                     __builtin_amdgcn_s_sleep(32);           // ~1 us between polls: hundreds of workgroups may be waiting (polling-cost, MI355X_MICROARCH.md)
                     if ((spins & 63u) != 0u) continue;      // the give-up word and the clock: every 64th poll
                     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { st = PIPE_FAIL; break; }
@@ -1108,9 +1241,9 @@ void sym_pipeline_f32(const PipeArgs a)
             uint32_t mask = 0;
             const u64_t want = k + 1;
             auto arrive = [&](uint32_t g, uint32_t bit) {
-                const u64_t old = __hip_atomic_fetch_add(a.done + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64_t old = __hip_atomic_fetch_add(PIPE_AT(a.done, g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old + 1 == (u64_t)a.expected[g] * want) {
-                    __hip_atomic_store(a.summable + g, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // waiters may start on the pieces at once
+                    __hip_atomic_store(PIPE_AT(a.summable, g), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // waiters may start on the pieces at once
                     mask |= 1u << bit;
                 }
             };
