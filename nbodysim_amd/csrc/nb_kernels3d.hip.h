@@ -582,16 +582,33 @@ void sym_gather3(const typename vec4_of<real>::type *__restrict__ slab_s, const 
     real4 a = make_real4<real>(0, 0, 0, 0);
     if (li < kn) {
         const uint32_t g = k / SYM_SB, loc = k % SYM_SB;
-        for (uint32_t r = row_lo[g] + q; r < row_hi[g]; r += GATHER_Q) {
+        const uint32_t r1 = row_hi[g];
+#pragma unroll 4      // four independent loads in flight per thread; the adds keep their order
+        for (uint32_t r = row_lo[g] + q; r < r1; r += GATHER_Q) {
             const real4 b = slab_s[(size_t)r * SYM_SB + loc];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
+        // coverage entries four at a time, as in sym_gather_block (nb_kernels.hip.h): descriptors, then the partials they point at,
+        // as independent batches; an entry that does not cover k reads element 0 of the slab and adds nothing; same order of adds
         const uint32_t c1 = cov_begin[g + 1];
-        for (uint32_t i = cov_begin[g] + q; i < c1; i += GATHER_Q) {
-            const SymCov cv = cov[i];
-            if (k < cv.lo || k >= cv.hi) continue;
-            const real4 b = slab_r[cv.base + (int64_t)k];
-            a.x += b.x; a.y += b.y; a.z += b.z;
+        for (uint32_t i = cov_begin[g] + q; i < c1; i += 4u * GATHER_Q) {
+            SymCov cv[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t idx = i + (uint32_t)u * GATHER_Q;
+                in[u] = idx < c1;
+                cv[u] = cov[in[u] ? idx : c1 - 1u];
+            }
+            real4 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                in[u] = in[u] && k >= cv[u].lo && k < cv[u].hi;
+                b[u] = slab_r[in[u] ? cv[u].base + (int64_t)k : (int64_t)0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (in[u]) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; }
         }
     }
     part[q][p] = a;

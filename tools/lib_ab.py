@@ -28,6 +28,10 @@ def child(cases, steps):
     for name in cases:
         if name.startswith("ref"):
             ic, kw, dt = nb.default_ics(int(name[3:])), dict(eps=1.0, extras=3), 0.01
+        elif name.startswith("q"):                   # 3-D
+            ic, kw, dt = nb.plummer_3d(int(name[1:]), 42), dict(eps=0.01, dims=3), 1e-3
+        elif name.startswith("d"):                   # fp64
+            ic, kw, dt = nb.plummer_2d(int(name[1:]), 42), dict(eps=0.01, precision="fp64"), 1e-3
         else:
             ic, kw, dt = nb.plummer_2d(int(name[1:]), 42), dict(eps=0.01), 1e-3
         for general in (False, True):
