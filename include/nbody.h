@@ -130,7 +130,8 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          force item — arrival, poll, acquire, gather — is as long as the launch boundary + gather launch it replaces.
                                          Not the default because its progress argument rests on workgroups being dispatched in index order, which
                                          HIP does not promise (a wait that does not end sets an error word within 4 s; the handle is then refused);
-                                         DESIGN.md 4.8 */
+                                         DESIGN.md 4.8.  Ignored where NB_FLAG_PIPELINE applies, and by handles that cannot step that way
+                                         (fp64, 3-D, KDK, sharded, one-sided: nb_describe says one_launch=0) */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange
