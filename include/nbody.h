@@ -118,11 +118,12 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          total momentum is conserved to that level only, not to rounding (measured in
                                          tests/test_headline_gpu.py); one more reason the flag is opt-in */
        NB_FLAG_PIPELINE        = 64,  /* EXPERIMENTAL, off by default: whole-system fp32 2-D handles run nb_step's whole loop as ONE persistent
-                                         launch (sym_pipeline_f32: in-order ticket queue, per-tile counters where the launch boundaries were,
-                                         cooperative gathers) instead of two launches per step.  Same sums, bit-identical results — and
-                                         SLOWER on MI355X at every size measured (+3 % at N = 262 144, +60 ... +240 % below 65 536: every
-                                         in-launch hand-off costs 15-25 us of fence / atomic / poll latency, the two launch boundaries and the
-                                         dedicated gather launch it replaces cost ~21 us per step in all) */
+                                         launch (sym_pipeline_f32: in-order ticket queue, two per-tile counters where the launch boundaries
+                                         were, the last item to arrive at a tile gathers it) instead of two launches per step.  Same sums,
+                                         bit-identical results.  Level with two launches per step from 131 072 bodies up (+-1 %), SLOWER below
+                                         (+4 ... +23 %: every tile meets every tile in every step, so at most a quarter of a step separates a
+                                         tile's last pair from its first pair of the next step, and the tickets in flight plus one item's
+                                         duration exceed that at small N) */
        NB_FLAG_ONE_LAUNCH_STEP = 128, /* EXPERIMENTAL, off by default: whole-system fp32 2-D kick-drift handles run a step as ONE launch (sym_step_f32:
                                          the gather + kick + drift workgroups follow the force items in the same grid and wait, tile by tile, for
                                          the items' arrivals; same sums, bit-identical results).  -0.5 ... -1.4 % per step at N = 25 000 ... 65 536,

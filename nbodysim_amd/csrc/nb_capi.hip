@@ -113,7 +113,7 @@ struct nb_sim {
     // persistent step pipeline (sym_pipeline_f32): nb_step(dt, nsteps) of a whole-system fp32 2-D handle is ONE launch
     bool pipe = false;                         // the handle's plan can run it (decided in plan_sym)
     bool pipe_failed = false;                  // a launch gave up (time-out word set): the counters are inconsistent, the handle is refused
-    u64_t *pipe_ctr = nullptr;                 // device: [head | done | summable | claim | fin | ready] (5 x tiles after the head)
+    u64_t *pipe_ctr = nullptr;                 // device: [head | done | ready] (tiles counters each after the head), one 128-byte line per counter
     uint32_t *pipe_expected_dev = nullptr;     // device: items touching each tile
     uint32_t *pipe_order_dev = nullptr;        // device: ticket -> item (the anti-diagonal order of the pipeline)
     int *pipe_err = nullptr;                   // page-locked host word the kernels set when a wait does not end
@@ -589,7 +589,7 @@ static int plan_sym(nb_sim *s)
             std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
             HIPCHK(hipMalloc((void **)&s->pipe_order_dev, order.size() * sizeof(uint32_t)));
             if ((rc = copy_h2d(s, s->pipe_order_dev, order.data(), order.size() * sizeof(uint32_t)))) return rc;
-            const size_t words = (1 + 5 * (size_t)tiles) * PIPE_CTR_STRIDE;     // [head | done | summable | claim | fin | ready], one 128-byte line per counter
+            const size_t words = (1 + 2 * (size_t)tiles) * PIPE_CTR_STRIDE;     // [head | done | ready], one 128-byte line per counter
             HIPCHK(hipMalloc((void **)&s->pipe_ctr, words * sizeof(u64_t)));
             HIPCHK(hipMemsetAsync(s->pipe_ctr, 0, words * sizeof(u64_t), s->stream));
             s->pipe = true;
@@ -1397,8 +1397,7 @@ static int launch_pipeline(nb_sim *s, float dt, int nsteps)
     a.expected = s->pipe_expected_dev;
     a.vel = (float2 *)s->vel; a.acc = (float2 *)s->acc;
     const size_t per = (size_t)s->sym_tiles * PIPE_CTR_STRIDE;
-    a.head = s->pipe_ctr; a.done = s->pipe_ctr + PIPE_CTR_STRIDE; a.summable = a.done + per; a.claim = a.summable + per;
-    a.fin = a.claim + per; a.ready = a.fin + per;
+    a.head = s->pipe_ctr; a.done = s->pipe_ctr + PIPE_CTR_STRIDE; a.ready = a.done + per;
     a.err = s->pipe_err;
     a.dbg = s->pipe_dbg;
     a.n = (uint32_t)s->n; a.n_items = s->sym_items; a.tiles = s->sym_tiles; a.sb_shift = s->sym_sb_shift;
@@ -1967,7 +1966,7 @@ extern "C" int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_
 
 // Debugging aid for the persistent step pipeline: with watch on, every workgroup of a launch keeps one page-locked host word
 // up to date with what it is doing (nb_kernels.hip.h: pipe_dbg); nb_debug_pipeline_state copies those words and the
-// pipeline's device counters [head | done | summable | claim | fin | ready] out WHILE a launch is running (own stream).
+// pipeline's device counters [head | done | ready] out WHILE a launch is running (own stream).
 extern "C" int nb_debug_pipeline_watch(nb_sim *s, int on)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_debug_pipeline_watch: NULL handle");
@@ -1988,8 +1987,8 @@ extern "C" int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t w
     if (tiles) *tiles = s->sym_tiles;
     if (workgroups && s->pipe_dbg) memcpy(workgroups, s->pipe_dbg, (wg_cap < PIPE_DBG_WORDS ? wg_cap : PIPE_DBG_WORDS) * sizeof(uint64_t));
     if (counters && s->dbg_stream) {
-        // the caller's view is compact ([head | done | summable | claim | fin | ready], tiles words each); on the device every counter has a line of its own
-        const size_t words = 1 + 5 * (size_t)s->sym_tiles, k = ctr_cap < words ? ctr_cap : words;
+        // the caller's view is compact ([head | done | ready], tiles words each); on the device every counter has a line of its own
+        const size_t words = 1 + 2 * (size_t)s->sym_tiles, k = ctr_cap < words ? ctr_cap : words;
         if (bind(s)) return NB_EHIP;
         std::vector<uint64_t> raw(words * PIPE_CTR_STRIDE);
         HIPCHK(hipMemcpyAsync(raw.data(), s->pipe_ctr, raw.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s->dbg_stream));
