@@ -120,6 +120,11 @@ struct nb_sim {
     u64_t pipe_epoch = 0, pipe_tickets = 0;    // steps / tickets the pipeline has completed so far (its counters are monotonic)
     uint32_t pipe_grid = 0;                    // resident workgroups of the variant this handle launches
     u64_t *pipe_dbg = nullptr;                 // nb_debug_pipeline_watch: page-locked host words, one per workgroup
+    // dynamic item tickets of the whole-system symmetric launch (sym_item_index, nb_kernels.hip.h)
+    uint32_t *sym_ticket = nullptr;            // device: one counter on a line of its own, monotonic modulo 2^32
+    uint32_t sym_ticket_base[3] = {0, 0, 0};   // what the launches so far have drawn, per launch kind (local or whole | cross | late: one counter each,
+                                               // 128 bytes apart — a sharded rank's launches may run side by side)
+    uint32_t sym_first_wave = 0;               // workgroups that keep their static item (the resident slots of the kernel variant); 0 = not yet known
     // one launch per step (sym_step_f32): the gather + kick + drift ride in the drain of the force launch
     bool fused = false;                        // the handle steps that way (decided in plan_sym; opt-in NB_FLAG_ONE_LAUNCH_STEP)
     uint32_t *step_done = nullptr;             // device: per-tile arrivals, monotonic modulo 2^32
@@ -549,6 +554,8 @@ static int plan_sym(nb_sim *s)
     // Persistent step pipeline (nb_kernels.hip.h: sym_pipeline_f32; EXPERIMENTAL, opt-in NB_FLAG_PIPELINE): whole-system fp32 2-D handles.  expected[g] = items
     // that touch tile g (their stationary tile, or a tile their travelling chunks lie in); an item's tiles must fit the
     // kernel's 32-bit "I was last" mask (1 + 31 tiles: any plan the planner sizes itself, not every forced one).
+    HIPCHK(hipMalloc((void **)&s->sym_ticket, 3 * 128));
+    HIPCHK(hipMemsetAsync(s->sym_ticket, 0, 3 * 128, s->stream));
     s->pipe = false;
     s->fused = false;
     const bool whole_f32 = s->sym && !split && !s->fp64 && !s->dims3 && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT;
@@ -630,7 +637,7 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
-    (void)hipFree(s->pipe_ctr); (void)hipFree(s->pipe_expected_dev); (void)hipFree(s->pipe_order_dev); (void)hipFree(s->step_done);
+    (void)hipFree(s->pipe_ctr); (void)hipFree(s->pipe_expected_dev); (void)hipFree(s->pipe_order_dev); (void)hipFree(s->step_done); (void)hipFree(s->sym_ticket);
     if (s->pipe_err) (void)hipHostFree(s->pipe_err);
     if (s->pipe_dbg) (void)hipHostFree(s->pipe_dbg);
     if (s->dbg_stream) (void)hipStreamDestroy(s->dbg_stream);
@@ -727,7 +734,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_PIPELINE | NB_FLAG_ONE_LAUNCH_STEP)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_PIPELINE | NB_FLAG_ONE_LAUNCH_STEP | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
@@ -923,17 +930,37 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
     const uint32_t n = (uint32_t)s->n;
     const SymItem *items = s->sym_items_dev + first;
     const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE;
+    // Dynamic work items (sym_item_index, nb_kernels.hip.h): past the first resident wave a workgroup draws its item when it starts.
+    // One counter per launch kind of the handle (this launch's is told by where its items begin), monotonic: `tb` = what the launches
+    // of that kind have drawn so far.
+    const uint32_t slot = first == 0 ? 0u : (first == s->sym_items_local ? 1u : 2u);
+    const bool dyn = s->sym_ticket != nullptr && !(s->p.flags & NB_FLAG_STATIC_ITEMS);
+    uint32_t *tk = nullptr;
+    uint32_t fw = 0, tb = 0;
+#define NB_TICKETS(KERNEL)                                                                                                        \
+    do {                                                                                                                          \
+        if (dyn) {                                                                                                                \
+            if (!s->sym_first_wave) {                                                                                             \
+                int per_cu = 0;                                                                                                   \
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, BLOCK, 0));                                  \
+                s->sym_first_wave = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)s->cus;                                       \
+            }                                                                                                                     \
+            fw = s->sym_first_wave < count ? s->sym_first_wave : count;                                                           \
+            tk = s->sym_ticket + slot * 32u; tb = s->sym_ticket_base[slot];                                                       \
+            s->sym_ticket_base[slot] += count - fw;                                                                               \
+        }                                                                                                                         \
+    } while (0)
     if (s->dims3 && s->fp64) {
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double4 *pos = (const double4 *)s->pos[s->cur];
         double4 *ss = (double4 *)s->sym_slab_s, *sr = (double4 *)s->sym_slab_r;
-        if (s->uniform_mass) force_sym3_f64<true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, (double)s->um_mass);
-        else                 force_sym3_f64<false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0);
+        if (s->uniform_mass) { NB_TICKETS(force_sym3_f64<true>);  force_sym3_f64<true><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, (double)s->um_mass, tk, fw, tb); }
+        else                 { NB_TICKETS(force_sym3_f64<false>); force_sym3_f64<false><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, 1.0, tk, fw, tb); }
     } else if (s->dims3) {
         const float eps2 = s->p.eps * s->p.eps;
         const float4 *pos = (const float4 *)s->pos[s->cur];
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
-#define NB_SYM3_LAUNCH(RQ, UMB, PR, UMV) force_sym3_f32<RQ, UMB, PR><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, UMV)
+#define NB_SYM3_LAUNCH(RQ, UMB, PR, UMV) do { NB_TICKETS((force_sym3_f32<RQ, UMB, PR>)); force_sym3_f32<RQ, UMB, PR><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, UMV, tk, fw, tb); } while (0)
         // chunk pairs in 3-D pay with equal masses only (-1 ... -3 %); with individual masses the pair body needs 216 VGPRs
         // (2 waves per SIMD) and loses 4 % (profiles/r03_chunk_pairs_3d.log): that case keeps the single-chunk sweep
         // (any plan, even chunk counts included, runs on either kernel) unless nb_params.sym_chunk_pairs = 1 forces it
@@ -950,18 +977,19 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         const double eps2 = (double)s->p.eps * (double)s->p.eps;
         const double2 *pos = (const double2 *)s->pos[s->cur];
         const double *mass = (const double *)s->mass;
-        if (s->uniform_mass) force_sym_f64<true><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass);
-        else                 force_sym_f64<false><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0);
+        if (s->uniform_mass) { NB_TICKETS(force_sym_f64<true>);  force_sym_f64<true><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, (double)s->um_mass, tk, fw, tb); }
+        else                 { NB_TICKETS(force_sym_f64<false>); force_sym_f64<false><<<count, BLOCK, 0, st>>>(pos, mass, items, (double2 *)s->sym_slab_s, (double2 *)s->sym_slab_r, n, eps2, 1.0, tk, fw, tb); }
     } else {
         const float eps2 = s->p.eps * s->p.eps;
         const float2 *pos = (const float2 *)s->pos[s->cur];
         const float *mass = (const float *)s->mass;
         float2 *ss = (float2 *)s->sym_slab_s, *sr = (float2 *)s->sym_slab_r;
         const float *sg = s->sigma;
+#define NB_SYM_GO(KERNEL, UMV) do { NB_TICKETS(KERNEL); KERNEL<<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV, tk, fw, tb); } while (0)
 #define NB_SYM_LAUNCH(RQ, MMODE, PR, UMV)                                                                                         \
         do {                                                                                                                      \
-            if (s->sym_sb == SYM_SB_WS) force_sym_f32<RQ, MMODE, PR, true><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV);  \
-            else                        force_sym_f32<RQ, MMODE, PR, false><<<count, BLOCK, 0, st>>>(pos, mass, sg, items, ss, sr, n, eps2, UMV); \
+            if (s->sym_sb == SYM_SB_WS) NB_SYM_GO((force_sym_f32<RQ, MMODE, PR, true>), UMV);                                     \
+            else                        NB_SYM_GO((force_sym_f32<RQ, MMODE, PR, false>), UMV);                                    \
         } while (0)
         const bool pairs = s->sym_pairs && !s->mass_scaled;          // chunk pairs (sym_chunks2): large systems, see want_pairs
         if (s->uniform_mass) {
@@ -974,7 +1002,9 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
             else       { if (pairs) NB_SYM_LAUNCH(RSQ_EXACT, MM_GENERAL, true, 1.0f); else NB_SYM_LAUNCH(RSQ_EXACT, MM_GENERAL, false, 1.0f); }
         }
 #undef NB_SYM_LAUNCH
+#undef NB_SYM_GO
     }
+#undef NB_TICKETS
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr, st)) return NB_EHIP;
     return NB_OK;

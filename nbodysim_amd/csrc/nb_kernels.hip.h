@@ -807,18 +807,38 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
     }
 }
 
+// Which item a workgroup runs.  Workgroups are dealt round-robin over the 8 XCDs and every XCD walks ITS share in index order
+// (tools/sym_timeline.hip: no inversion inside an XCD, XCDs up to 8 % of a launch apart), so with item = blockIdx every XCD gets
+// the same work — and the XCDs of one part are not equally fast: the same XCDs end 2-5 % before the others launch after launch,
+// whatever items they were dealt (profiles/r04_xcd_speed.log), and stand idle until the slowest is through.  With `ticket` set, the
+// workgroups of the first wave (blockIdx < first_wave: they start together, an atomic each would only queue them up) keep their
+// static item and every later workgroup draws the next item of the list when it STARTS: a faster XCD starts more workgroups and so
+// takes more items.  The counter is monotonic over the handle's life (base = what earlier launches drew); any order gives the same
+// bits, every item writes its own slab rows.
+__device__ __forceinline__ uint32_t sym_item_index(uint32_t *ticket, uint32_t first_wave, uint32_t base)
+{
+    uint32_t idx = blockIdx.x;
+    if (ticket != nullptr && idx >= first_wave) {             // uniform over the workgroup
+        __shared__ uint32_t sh_idx;
+        if (threadIdx.x == 0) sh_idx = first_wave + (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base);
+        __syncthreads();
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_idx);
+    }
+    return idx;
+}
+
 template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
 void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                    const SymItem *__restrict__ items,
                    float2 *__restrict__ slab_s, float2 *__restrict__ slab_r,
-                   uint32_t n, float eps2, float um_mass)
+                   uint32_t n, float eps2, float um_mass, uint32_t *ticket, uint32_t first_wave, uint32_t ticket_base)
 {
 #ifndef NB_SYM_WT
 #define NB_SYM_WT true       // write-through (sc1) slab stores: the partials are read by the NEXT launch only, so nothing is gained by
 #endif                       // keeping them dirty in this XCD's L2 until the kernel's end flushes them: -1.8 % step time at N = 25 000,
                              // -0.7 % at 65 536, neutral at 262 144, same bits (tools/wt_ab.sh, profiles/r04_write_through_ab.log)
-    force_sym_f32_body<RSQ, MM, PAIRS, WS, NB_SYM_WT>(pos, mass, sigma, items[blockIdx.x], slab_s, slab_r, n, eps2, um_mass);
+    force_sym_f32_body<RSQ, MM, PAIRS, WS, NB_SYM_WT>(pos, mass, sigma, items[sym_item_index(ticket, first_wave, ticket_base)], slab_s, slab_r, n, eps2, um_mass);
 }
 
 // sigma[i] = m_i^(-1/2) for the mass-scaled kernels (correctly rounded sqrt and divide)
@@ -1383,11 +1403,11 @@ __global__ __launch_bounds__(BLOCK)
 void force_sym_f64(const double2 *__restrict__ pos, const double *__restrict__ mass,
                    const SymItem *__restrict__ items,
                    double2 *__restrict__ slab_s, double2 *__restrict__ slab_r,
-                   uint32_t n, double eps2, double um_mass)
+                   uint32_t n, double eps2, double um_mass, uint32_t *ticket, uint32_t first_wave, uint32_t ticket_base)
 {
     static_assert(64 * SYM_P64 == SYM_WT, "fp64 and fp32 symmetric kernels share the tile geometry");
     __shared__ double2 red[2][4][64];
-    const SymItem it = items[blockIdx.x];
+    const SymItem it = items[sym_item_index(ticket, first_wave, ticket_base)];
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     double xi[SYM_P64], yi[SYM_P64], mi[SYM_P64], ax[SYM_P64], ay[SYM_P64];
     uint32_t li[SYM_P64];

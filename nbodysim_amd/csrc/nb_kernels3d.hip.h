@@ -361,10 +361,11 @@ void sym3_chunks2(const float4 *__restrict__ pos, float4 *__restrict__ slab_r_ro
 template <int RSQ, bool UM, bool PAIRS = false>
 __global__ __launch_bounds__(BLOCK)
 void force_sym3_f32(const float4 *__restrict__ pos, const SymItem *__restrict__ items,
-                    float4 *__restrict__ slab_s, float4 *__restrict__ slab_r, uint32_t n, float eps2, float um_mass)
+                    float4 *__restrict__ slab_s, float4 *__restrict__ slab_r, uint32_t n, float eps2, float um_mass,
+                    uint32_t *ticket, uint32_t first_wave, uint32_t ticket_base)
 {
     __shared__ float4 red[PAIRS ? 4 : 2][4][64];
-    const SymItem it = items[blockIdx.x];
+    const SymItem it = items[sym_item_index(ticket, first_wave, ticket_base)];
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     v2f xi[SYM_P], yi[SYM_P], zi[SYM_P], mi[SYM_P], ax[SYM_P], ay[SYM_P], az[SYM_P];
     uint32_t li[SYM_P];
@@ -536,10 +537,11 @@ void sym3_chunks_f64(const double4 *__restrict__ pos, double4 *__restrict__ slab
 template <bool UM>
 __global__ __launch_bounds__(BLOCK)
 void force_sym3_f64(const double4 *__restrict__ pos, const SymItem *__restrict__ items,
-                    double4 *__restrict__ slab_s, double4 *__restrict__ slab_r, uint32_t n, double eps2, double um_mass)
+                    double4 *__restrict__ slab_s, double4 *__restrict__ slab_r, uint32_t n, double eps2, double um_mass,
+                    uint32_t *ticket, uint32_t first_wave, uint32_t ticket_base)
 {
     __shared__ double4 red[2][4][64];
-    const SymItem it = items[blockIdx.x];
+    const SymItem it = items[sym_item_index(ticket, first_wave, ticket_base)];
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     double xi[SYM_P64], yi[SYM_P64], zi[SYM_P64], mi[SYM_P64], ax[SYM_P64], ay[SYM_P64], az[SYM_P64];
     uint32_t li[SYM_P64];

@@ -68,6 +68,7 @@ class Simulation:
         pos_rows: int = 0,
         pipeline: bool = False,
         one_launch: bool = False,
+        static_items: bool = False,
     ):
         """The last arguments (from ``uniform_mass`` on) are ``nb_params.flags`` and the launch-geometry tuning fields
         (0 / True = the library's automatic choice); the library reads no environment variables."""
@@ -97,7 +98,7 @@ class Simulation:
         p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
                    | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL) | (L.NB_FLAG_SHARD_ALLREDUCE if shard_allreduce else 0)
                    | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0) | (L.NB_FLAG_MASS_SCALING if mass_scaling else 0)
-                   | (L.NB_FLAG_PIPELINE if pipeline else 0) | (L.NB_FLAG_ONE_LAUNCH_STEP if one_launch else 0))
+                   | (L.NB_FLAG_PIPELINE if pipeline else 0) | (L.NB_FLAG_ONE_LAUNCH_STEP if one_launch else 0) | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail

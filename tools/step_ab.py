@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--general", action="store_true")
+    ap.add_argument("--what", default="one_launch", choices=("one_launch", "dynamic_items"), help="the switch under test: one launch per step against two (default), or dynamic against static work items")
     ap.add_argument("--extra", default="", help="comma-separated key=int tuning fields passed to both sides")
     args = ap.parse_args()
     extra = {k: int(v) for k, v in (kv.split("=") for kv in args.extra.split(",") if kv)}
@@ -65,6 +66,13 @@ def main():
                 kw["uniform_mass"] = False
             steps = max(20, min(args.steps, int(args.steps * (65536.0 / n) ** 2)))
             frac = lambda ms: 14.0 * n * n / (ms * 1e-3) / PEAK
+            if args.what == "dynamic_items":
+                two, info, d2, e2 = run(ic, kw, dt, steps, args.reps, static_items=True, **extra)
+                one, _, d1, e1 = run(ic, kw, dt, steps, args.reps, static_items=False, **extra)
+                print(f"round {rnd + 1} {name:10s} n={n:7d} tile={info['tile_particles']:4d} L={info['chunks_per_item']:3d} items={info['items']:5d} steps={steps:3d} | "
+                      f"static items {two*1e3:9.1f} us/step frac {frac(two):.3f} | dynamic items {one*1e3:9.1f} us/step frac {frac(one):.3f} "
+                      f"({(one/two-1)*100:+.1f} %) | bit-identical {same(e1, e2)}", flush=True)
+                continue
             two, info, d2, e2 = run(ic, kw, dt, steps, args.reps, one_launch=False, **extra)
             one, _, d1, e1 = run(ic, kw, dt, steps, args.reps, one_launch=True, **extra)
             assert "one_launch=0" in d2 and "one_launch=1" in d1, (d1, d2)

@@ -8,7 +8,7 @@
 // workgroup end to the last one).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Inbodysim_amd/csrc -Iinclude -o build/sym_timeline tools/sym_timeline.hip nbodysim_amd/csrc/nb_plan.cpp
-//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [general=1] [pairs=0] [reps=20]
+//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [general=1] [pairs=0] [reps=20] [shift=0]
 #include "nb_kernels.hip.h"
 
 #include <algorithm>
@@ -28,17 +28,18 @@ struct Stamp { unsigned long long t0, t1, c0, c1; unsigned hw_id, xcc_id; };
 
 template <int MM, bool PAIRS, bool WS>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
-void stamped(const float2 *pos, const float *mass, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st)
+void stamped(const float2 *pos, const float *mass, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st, uint32_t shift)
 {
+    if (blockIdx.x < shift) return;                     // `shift` idle workgroups in front: item i runs as workgroup i + shift (moves every item to another XCD)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
-    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items[blockIdx.x], slab_s, slab_r, n, eps2, um);
+    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items[blockIdx.x - shift], slab_s, slab_r, n, eps2, um);
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) {
         Stamp s;
         s.t0 = t0; s.t1 = t1; s.c0 = c0; s.c1 = c1;
         s.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         s.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-        st[blockIdx.x] = s;
+        st[blockIdx.x - shift] = s;
     }
 }
 
@@ -50,6 +51,7 @@ int main(int argc, char **argv)
     const bool general = argc > 4 ? atoi(argv[4]) != 0 : true;
     const bool pairs = argc > 5 ? atoi(argv[5]) != 0 : false;
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
+    const uint32_t shift = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
 
@@ -70,7 +72,7 @@ int main(int argc, char **argv)
     const uint32_t grid = (uint32_t)pl.items.size();
     const float eps2 = 1e-4f, um = 1.0f / n;
     auto launch = [&]() {
-#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid, BLOCK>>>(pos, mass, items, ss, sr, n, eps2, um, st)
+#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid + shift, BLOCK>>>(pos, mass, items, ss, sr, n, eps2, um, st, shift)
         if (tile == SYM_SB_WS) { if (general) { if (pairs) GO(MM_GENERAL, true, true); else GO(MM_GENERAL, false, true); }
                                  else         { if (pairs) GO(MM_UNIFORM, true, true); else GO(MM_UNIFORM, false, true); } }
         else                   { if (general) { if (pairs) GO(MM_GENERAL, true, false); else GO(MM_GENERAL, false, false); }
@@ -128,6 +130,39 @@ int main(int argc, char **argv)
            mhz, (int)simds, ideal_us, work / simds / 2400.0);
     printf("  inside the kernel: first start -> last end %.1f us | last workgroup START at %.1f us (90%% started by %.1f)\n",
            (tmax - tmin) * 0.01, (last_start - tmin) * 0.01, starts[(size_t)(0.9 * grid)]);
+    // dispatch order: does a workgroup ever start before one of LOWER index?  (running maximum of the start times in index order:
+    // an inversion is a workgroup that starts more than `slack` before that maximum).  HIP promises no order; this is what is observed.
+    {
+        unsigned long long run_max = 0; size_t inv1 = 0, inv10 = 0; double worst = 0.0;
+        for (uint32_t i = 0; i < grid; ++i) {
+            if (hs[i].t0 + 100 < run_max) ++inv1;                  // > 1 us earlier than an earlier-indexed workgroup's start
+            if (hs[i].t0 + 1000 < run_max) ++inv10;                // > 10 us
+            if (run_max > hs[i].t0) worst = std::max(worst, (run_max - hs[i].t0) * 0.01);
+            run_max = std::max(run_max, hs[i].t0);
+        }
+        printf("  dispatch order: %zu of %u workgroups started > 1 us before a lower-indexed one (%zu by > 10 us; largest inversion %.2f us)\n", inv1, grid, inv10, worst);
+        // the same among the workgroups of ONE XCD (workgroups are dealt round-robin over the XCDs and each XCD walks its share on its own)
+        std::map<unsigned, unsigned long long> xmax; size_t xinv1 = 0; double xworst = 0.0; size_t rr_ok = 0;
+        const unsigned x0 = hs[0].xcc_id & 0xf;
+        for (uint32_t i = 0; i < grid; ++i) {
+            const unsigned x = hs[i].xcc_id & 0xf;
+            if (((x + 8u - x0) & 7u) == (i & 7u)) ++rr_ok;
+            unsigned long long &m = xmax[x];
+            if (hs[i].t0 + 100 < m) ++xinv1;
+            if (m > hs[i].t0) xworst = std::max(xworst, (m - hs[i].t0) * 0.01);
+            m = std::max(m, hs[i].t0);
+        }
+        {   // per XCD: VALU work dealt to it and when its last workgroup ended
+            std::map<unsigned, double> xw; std::map<unsigned, unsigned long long> xe;
+            double wsum = 0;
+            for (uint32_t i = 0; i < grid; ++i) { const unsigned x = hs[i].xcc_id & 0xf; xw[x] += item_cyc[i]; wsum += item_cyc[i]; xe[x] = std::max(xe[x], hs[i].t1); }
+            printf("  workgroup 0 sits on XCD %u; per XCD (work / mean, last end in us):", hs[0].xcc_id & 0xf);
+            for (auto &kv : xw) printf("  %u: %.3f %.1f", kv.first, kv.second / (wsum / xw.size()), (xe[kv.first] - tmin) * 0.01);
+            printf("\n");
+        }
+        printf("  ... within one XCD: %zu workgroups started > 1 us before a lower-indexed one of the same XCD (largest inversion %.2f us); "
+               "%zu of %u workgroups sit on XCD (index mod 8) + const\n", xinv1, xworst, rr_ok, grid);
+    }
     printf("  workgroup duration: min %.1f median %.1f p90 %.1f max %.1f us\n", dur.front(), dur[grid / 2], dur[(size_t)(0.9 * grid)], dur.back());
     printf("  workgroup ends: 10%% %.1f median %.1f 90%% %.1f last %.1f us\n", ends[(size_t)(0.1 * grid)], ends[grid / 2], ends[(size_t)(0.9 * grid)], ends.back());
     printf("  per CU: items min %d max %d | VALU work max / mean = %.3f, min / mean = %.3f -> busiest CU alone needs %.1f us at that clock\n",
