@@ -159,6 +159,15 @@ int main(int argc, char **argv)
             printf("  workgroup 0 sits on XCD %u; per XCD (work / mean, last end in us):", hs[0].xcc_id & 0xf);
             for (auto &kv : xw) printf("  %u: %.3f %.1f", kv.first, kv.second / (wsum / xw.size()), (xe[kv.first] - tmin) * 0.01);
             printf("\n");
+            // shader clock seen by the workgroups of each XCD (s_memtime ticks per 100 MHz tick, workgroups longer than 1 us)
+            std::map<unsigned, double> xc; std::map<unsigned, size_t> xn;
+            for (uint32_t i = 0; i < grid; ++i) {
+                const Stamp &q = hs[i];
+                if (q.t1 > q.t0 + 100) { xc[q.xcc_id & 0xf] += (double)(q.c1 - q.c0) / (double)(q.t1 - q.t0) * 100.0; ++xn[q.xcc_id & 0xf]; }
+            }
+            printf("  per XCD shader clock (MHz):");
+            for (auto &kv : xc) printf("  %u: %.0f", kv.first, kv.second / (double)xn[kv.first]);
+            printf("\n");
         }
         printf("  ... within one XCD: %zu workgroups started > 1 us before a lower-indexed one of the same XCD (largest inversion %.2f us); "
                "%zu of %u workgroups sit on XCD (index mod 8) + const\n", xinv1, xworst, rr_ok, grid);
