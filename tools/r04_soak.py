@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long runs of the hand-off heavy paths of round 4, compared bit for bit against their references:
   * the experimental step pipeline (one persistent launch per batch of steps) and the one-launch step (gather workgroups in the
-    drain of the force launch) against two launches per step;
+    drain of the force launch) against two launches per step, with dynamic (default) and static work items;
   * (python tests/loopback_worker.py covers the C loop over the loopback transport: here only its step count is raised).
     python tools/r04_soak.py"""
 import sys, time
@@ -19,16 +19,16 @@ for name, n, kw, dt, batches in (("p16384", 16384, dict(eps=0.05), 1e-3, [1000] 
                                  ("p262144", 262144, dict(eps=0.01), 1e-3, [60] * 3)):
     ic = nb.default_ics(n) if name.startswith("ref") else nb.plummer_2d(n, 42)
     t0 = time.time()
-    with nb.Simulation(ic, pipeline=True, **kw) as a, nb.Simulation(ic, pipeline=False, **kw) as b, nb.Simulation(ic, one_launch=True, **kw) as c:
+    with nb.Simulation(ic, pipeline=True, **kw) as a, nb.Simulation(ic, pipeline=False, **kw) as b, nb.Simulation(ic, one_launch=True, **kw) as c, nb.Simulation(ic, static_items=True, **kw) as d:
         total, ok = 0, True
         for k in batches:
-            a.advance(k, dt); b.advance(k, dt); c.advance(k, dt)
-            x, y, z = a.sync(), b.sync(), c.sync()
+            a.advance(k, dt); b.advance(k, dt); c.advance(k, dt); d.advance(k, dt)
+            x, y, z, w = a.sync(), b.sync(), c.sync(), d.sync()
             total += k
-            same = all(np.array_equal(bits(x[f]), bits(y[f])) and np.array_equal(bits(z[f]), bits(y[f])) for f in ("pos", "vel", "acc"))
+            same = all(np.array_equal(bits(x[f]), bits(y[f])) and np.array_equal(bits(z[f]), bits(y[f])) and np.array_equal(bits(w[f]), bits(y[f])) for f in ("pos", "vel", "acc"))
             ok = ok and same
             if not same:
                 bad = int(np.sum(np.any(bits(x["pos"]) != bits(y["pos"]), axis=1)))
                 print(f"   {name}: MISMATCH after {total} steps: {bad} bodies differ", flush=True)
                 break
-    print(f"{name}: {total} steps, pipeline == one launch per step == two launches per step, bit for bit: {ok}  ({time.time() - t0:.1f} s)", flush=True)
+    print(f"{name}: {total} steps, pipeline == one launch per step == two launches per step (dynamic items) == two launches (static items), bit for bit: {ok}  ({time.time() - t0:.1f} s)", flush=True)
