@@ -501,10 +501,10 @@ int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *t
                       nb_sym_item *items_out, size_t cap, nb_sym_info *info);
 
 /* Debugging aid for the persistent step pipeline (whole-system fp32 2-D handles run nb_step's loop as ONE launch): with watch
- * on, every workgroup keeps a page-locked host word saying what it is doing (code << 56 | tile << 32 | ticket / step / piece;
- * codes: 1 drew a ticket, 2 waits for a tile, 3 helps with a tile's gather, 4 item body, 5 arrived, 6 left, 7 gathers a piece);
- * nb_debug_pipeline_state copies those words and the pipeline's device counters [queue head | done | summable | claim | fin |
- * ready] (5 x tiles after the head) out while a launch is running. */
+ * on, every workgroup keeps a page-locked host word saying what it is doing (code << 56 | tile << 32 | ticket / step;
+ * codes: 1 drew a ticket, 2 waits for a tile, 4 item body, 5 arrived, 6 left, 7 gathers a tile);
+ * nb_debug_pipeline_state copies those words and the pipeline's device counters [queue head | done | ready] (2 x tiles after
+ * the head) out while a launch is running. */
 int nb_debug_pipeline_watch(nb_sim *s, int on);
 int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t wg_cap, uint64_t *counters, size_t ctr_cap, uint32_t *tiles);
 
