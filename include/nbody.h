@@ -508,6 +508,10 @@ int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *t
 int nb_debug_pipeline_watch(nb_sim *s, int on);
 int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t wg_cap, uint64_t *counters, size_t ctr_cap, uint32_t *tiles);
 
+/* Test hook for the dynamic work items (NB_FLAG_STATIC_ITEMS above): sets the handle's item-ticket counters, and the host's record of
+ * what has been drawn, to `value` — a test steps a handle across the 2^32 wrap of the counters this way.  Waits for the handle's streams. */
+int nb_debug_ticket_seed(nb_sim *s, uint32_t value);
+
 /* Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) exactly as the device kernels evaluate it, on an array of n (even)
  * floats: y_scalar through the scalar form (reference-order kernel), y_packed through the packed form (tiled and
  * symmetric kernels).  Test hook for the bit-exact check against the reference's golden grid. */

@@ -207,6 +207,7 @@ PROTOTYPES = {
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_default_ics": (C.c_int, [C.c_void_p, C.c_size_t]),
     "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(nb_params), C.c_void_p, C.c_size_t, C.POINTER(nb_sym_info)]),
+    "nb_debug_ticket_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
     "nb_debug_pipeline_watch": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_debug_pipeline_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "nb_sym_plan_info": (C.c_int, [C.c_void_p, C.POINTER(nb_sym_info)]),

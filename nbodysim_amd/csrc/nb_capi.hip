@@ -2028,6 +2028,23 @@ extern "C" int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t w
     return NB_OK;
 }
 
+// Test hook: move the handle's item-ticket counters (device) and the host's record of them to `value`, as if the launches so far
+// had drawn that many items — so that a test can step a handle ACROSS the 2^32 wrap of the counters (580 000 steps away at
+// N = 262 144) in a few steps.
+extern "C" int nb_debug_ticket_seed(nb_sim *s, uint32_t value)
+{
+    if (!s) return nb_fail(NB_EINVAL, "nb_debug_ticket_seed: NULL handle");
+    if (!s->sym_ticket) return nb_fail(NB_ESTATE, "nb_debug_ticket_seed: the handle has no symmetric plan");
+    if (bind(s)) return NB_EHIP;
+    if (s->aux) HIPCHK(hipStreamSynchronize(s->aux));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    uint32_t words[3 * 32];
+    memset(words, 0, sizeof words);
+    for (int k = 0; k < 3; ++k) { words[k * 32] = value; s->sym_ticket_base[k] = value; }
+    HIPCHK(hipMemcpy(s->sym_ticket, words, sizeof words, hipMemcpyHostToDevice));
+    return NB_OK;
+}
+
 extern "C" int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out)
 {
     if (!s || !out) return nb_fail(NB_EINVAL, "nb_sym_plan_info: NULL argument");

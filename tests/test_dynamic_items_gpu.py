@@ -71,3 +71,20 @@ def test_the_launch_kinds_of_a_sharded_rank_draw_from_their_own_counters(allredu
             s.wait()
             out.append(s.sync().copy())
     assert _same(out[0], out[1])
+
+
+def test_the_ticket_counters_wrap_around_2_to_the_32():
+    """The counters are monotonic modulo 2^32 (no reset between launches): seeded 1 000 draws short of the wrap, a handle whose
+    launches draw ~2 700 items each steps across it; same bits as static items."""
+    n = 65536
+    ic = nb.plummer_2d(n, 11)
+    lib = nb.load()
+    with nb.Simulation(ic, eps=0.02, static_items=True) as s:
+        s.advance(6, 1e-3)
+        want = s.sync().copy()
+    with nb.Simulation(ic, eps=0.02) as s:
+        assert s.sym_info()["items"] > 2000
+        L.check("nb_debug_ticket_seed", lib.nb_debug_ticket_seed(s._h, 2 ** 32 - 1000))
+        s.advance(6, 1e-3)
+        got = s.sync().copy()
+    assert _same(got, want)
