@@ -126,8 +126,8 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          duration exceed that at small N) */
        NB_FLAG_ONE_LAUNCH_STEP = 128, /* EXPERIMENTAL, off by default: whole-system fp32 2-D kick-drift handles run a step as ONE launch (sym_step_f32:
                                          the gather + kick + drift workgroups follow the force items in the same grid and wait, tile by tile, for
-                                         the items' arrivals; same sums, bit-identical results).  -0.5 ... -1.4 % per step at N = 25 000 ... 65 536,
-                                         +1.5 % at 16 384, within the noise from 131 072 up (profiles/r04_one_launch_ab.log): what follows the last
+                                         the items' arrivals; same sums, bit-identical results).  -1.1 ... -1.7 % per step at N = 49 152 ... 65 536,
+                                         -0.3 ... -0.6 % from 131 072 up, +0.5 ... +1.3 % below 49 152 (profiles/r04_one_launch_ab.log): what follows the last
                                          force item — arrival, poll, acquire, gather — is as long as the launch boundary + gather launch it replaces.
                                          Not the default because its progress argument rests on workgroups being dispatched in index order, which
                                          HIP does not promise (a wait that does not end sets an error word within 4 s; the handle is then refused);

@@ -1119,10 +1119,26 @@ static int launch_sym_step(nb_sim *s, float dt)
     const bool pairs = s->sym_pairs && !s->mass_scaled;
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
+    // the force part draws its items from the handle's whole-system counter (slot 0), like launch_sym_items
+    const bool dyn = s->sym_ticket != nullptr && !(s->p.flags & NB_FLAG_STATIC_ITEMS);
+#define NB_STEP_ONE(KERNEL)                                                                                          \
+    do {                                                                                                             \
+        if (dyn) {                                                                                                   \
+            if (!s->sym_first_wave) {                                                                                \
+                int per_cu = 0;                                                                                      \
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, BLOCK, 0));                     \
+                s->sym_first_wave = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)s->cus;                          \
+            }                                                                                                        \
+            a.first_wave = s->sym_first_wave < s->sym_items ? s->sym_first_wave : s->sym_items;                      \
+            a.ticket = s->sym_ticket; a.ticket_base = s->sym_ticket_base[0];                                         \
+            s->sym_ticket_base[0] += s->sym_items - a.first_wave;                                                    \
+        }                                                                                                            \
+        KERNEL<<<grid, BLOCK, 0, s->stream>>>(a);                                                                    \
+    } while (0)
 #define NB_STEP_GO(RQ, MMODE, PR)                                                                                   \
     do {                                                                                                             \
-        if (ws) sym_step_f32<RQ, MMODE, PR, true><<<grid, BLOCK, 0, s->stream>>>(a);                                 \
-        else    sym_step_f32<RQ, MMODE, PR, false><<<grid, BLOCK, 0, s->stream>>>(a);                                \
+        if (ws) NB_STEP_ONE((sym_step_f32<RQ, MMODE, PR, true>));                                                    \
+        else    NB_STEP_ONE((sym_step_f32<RQ, MMODE, PR, false>));                                                   \
     } while (0)
     if (s->uniform_mass) {
         if (quake) { if (pairs) NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, true); else NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, false); }
@@ -1134,6 +1150,7 @@ static int launch_sym_step(nb_sim *s, float dt)
         else       { if (pairs) NB_STEP_GO(RSQ_EXACT, MM_GENERAL, true); else NB_STEP_GO(RSQ_EXACT, MM_GENERAL, false); }
     }
 #undef NB_STEP_GO
+#undef NB_STEP_ONE
     HIPCHK(hipGetLastError());
     if (s->prof && prof_end(s, pr)) return NB_EHIP;
     return NB_OK;

@@ -1012,6 +1012,8 @@ struct StepArgs {
     uint32_t n, n_items, sb_shift, epoch;
     float eps2, um_mass, dt;
     int extras;
+    uint32_t *ticket;                // dynamic work items of the force part (sym_item_index); NULL = item = workgroup index
+    uint32_t first_wave, ticket_base;
 };
 constexpr uint32_t STEP_CTR_STRIDE = 32;     // words between two tiles' counters: one 128-byte line each (arrivals and polls of different tiles do not queue behind each other)
 
@@ -1021,7 +1023,7 @@ void sym_step_f32(const StepArgs a)
 {
     const uint32_t t = threadIdx.x;
     if (blockIdx.x < a.n_items) {
-        const SymItem it = a.items[blockIdx.x];
+        const SymItem it = a.items[sym_item_index(a.ticket, a.first_wave, a.ticket_base)];     // a force workgroup draws its item like any other
         force_sym_f32_body<RSQ, MM, PAIRS, WS, true>(a.pos_cur, a.mass, a.sigma, it, a.slab_s, a.slab_r, a.n, a.eps2, a.um_mass);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through slab stores have left
         __syncthreads();                                     // ... every wave's
