@@ -261,10 +261,11 @@ static bool sym_eligible(const nb_sim *s)
     if (s->p.sum_order != NB_SUM_TILED || needs_guard(s)) return false;
     if (s->fp64 && s->p.rsqrt_mode != NB_RSQRT_EXACT) return false;
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
-    // smallest system worth the symmetric scheme: 16 384 bodies with the classic tiles (rounds 1-3); with the wave-split tiles it
-    // overtakes the one-sided kernel from ~9 000 bodies on (-12 % at 10 000, -13 % at 12 288, -19 % at 14 336; +4 ... +7 % at 8 192:
-    // tools/small_n_check.py, profiles/r04_small_n_check.log)
-    if (s->n < (sym_tile_of(s->p, s->n) == SYM_SB_WS ? (size_t)9216 : 8 * (size_t)SYM_SB)) return false;
+    // smallest system worth the symmetric scheme: 16 384 bodies with the classic tiles (rounds 1-3); with the wave-split tiles and
+    // their uniform one-chunk-per-wave plans it overtakes the one-sided kernel from ~5 600 bodies on (-4 ... -8 % at 5 632, -14 ... -17 %
+    // at 6 144, -24 ... -28 % at 7 168, -32 ... -34 % at 10 000; +1 ... +6 % at 5 120, +25 % at 4 096: tools/one_wave_check.py,
+    // profiles/r04_small_n_plans.log)
+    if (s->n < (sym_tile_of(s->p, s->n) == SYM_SB_WS ? (size_t)5632 : 8 * (size_t)SYM_SB)) return false;
     const uint32_t world = s->p.shard_world > 1 ? (uint32_t)s->p.shard_world : 1u;
     // Travelling partials: one element per (tile, later particle) pair the handle evaluates — tiles x n / 2 for a
     // whole system (1 GiB at N = 524 288 fp32, 2 GiB at 1 048 576, 32 GiB at 4 194 304), 1/world of that for a rank.

@@ -103,7 +103,25 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // chunk pairs: even counts; wave-split tiles: one chunk (pair) per wave, i.e. multiples of 4 (8) — a forced L is taken as given
     const uint32_t unit = tune.quantum();
     if (unit > 1 && !tune.forced_L) L = L < unit ? unit : ((L + unit / 2) / unit) * unit;
-
+    // WAVE-SPLIT plans of whole systems (round 4; tiles of 512, N < 49 152): the finest uniform items and NO guided tail.  With one
+    // chunk per wave a workgroup is one chunk time long (7.3 us with equal masses), a CU holding k of them takes k chunk times, and
+    // the measured step is 9.1 + 7.3 x ceil(items / CUs) us from 7 168 to 25 000 bodies (profiles/r04_small_n_plans.log) — what
+    // counts is the item COUNT.  Tail pieces of such items hold fewer chunks than the workgroup has waves (idle waves, nothing
+    // gained) and only raise the count; coarser items (the rule above: ~16 sqrt(units)) quantise the same work into fewer, longer
+    // rounds.  Against the plans of earlier in the round: -21 % per step at N = 7 168 / 10 000 / 11 000, -16 % at 13 312, -8 ... -10 %
+    // at 14 336 ... 20 000, -15 % at 21 000 / 22 000, -5.5 % at 25 000 (the reference's own workload: 97.9 -> 92.3 us), -3 % at
+    // 32 768 / 36 000; two sizes lose 2-4 % to a plan of 8 chunks per item (12 288, 16 384).  Beyond ~25 items per CU the count no
+    // longer quantises and the per-item costs show: from there 8 chunks per item with the late tail (40 000 ... 49 151: -1 ... -2 %).
+    bool no_tail = false, late_tail = false;
+    if (!tune.forced_L && !tune.tail_given && world == 1 && g.sb == SYM_SB_WS && tune.guided_tail) {
+        uint64_t items = 0;
+        for (uint32_t I = 0; I < tiles; ++I) {
+            const uint32_t d0 = I * g.cpt, dend = g.diag_end(I);
+            items += (dend - d0 + unit - 1) / unit + (chunks - dend + unit - 1) / unit;
+        }
+        if (items <= 25ull * cus) { L = unit; no_tail = true; }
+        else { L = 2 * unit; late_tail = true; }
+    }
     // Cross items: EVERY tile's range of later-block chunks [be, chunks) is cut into `world` contiguous sub-ranges and
     // rank r takes sub-range (r + I) mod world of tile I.  Every rank therefore holds a slice of every tile: its stationary
     // rows and travelling segments — and with them the work of its sym_gather — are spread over all tiles instead of
@@ -164,7 +182,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // 7 % of a rank's step at world = 8).  The end of each launch's work is cut into finer items
     // (L/2, L/4, L/8 chunks from 85 %, 94 %, 98 % of the work on; profiles/r01_guided_tail_ab.log): -2 % step time.
     // Splitting happens after the cross runs were assigned, so every rank still sees the same run boundaries.
-    if (tune.guided_tail) {
+    if (tune.guided_tail && !no_tail) {
         auto guided = [&](std::vector<SymItem> &list, std::vector<uint32_t> &rows_of) {
             uint64_t total = 0, done = 0;
             for (const auto &it : list) total += it.cnt;
@@ -174,7 +192,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
             // — 6 100 items before the tail is cut, 8 187 after: 6 rounds — unchanged; profiles/r04_tail_sweep.log, r04_defaults_check.log).  Explicit
             // thresholds (nb_params.sym_tail) are taken as given.
             double at[3] = {tune.tail_at[0], tune.tail_at[1], tune.tail_at[2]};
-            if (!tune.tail_given && world == 1 && (double)list.size() < 5.0 * 4.0 * (double)cus) { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }
+            if (!tune.tail_given && world == 1 && !late_tail && (double)list.size() < 5.0 * 4.0 * (double)cus) { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }
             std::vector<SymItem> out;
             out.reserve(list.size() * 2);
             for (const auto &it : list) {
