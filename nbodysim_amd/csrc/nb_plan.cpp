@@ -190,9 +190,12 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
             // last, partly filled round: the finer items start earlier there (0.65 / 0.85 / 0.95 below 5 rounds instead of 0.85 / 0.94 /
             // 0.98: -9 % at N = 16 384 (with tail pieces of fewer chunks than waves), -1 % at 65 536, +-1 % elsewhere, the headline plan
             // — 6 100 items before the tail is cut, 8 187 after: 6 rounds — unchanged; profiles/r04_tail_sweep.log, r04_defaults_check.log).  Explicit
-            // thresholds (nb_params.sym_tail) are taken as given.
+            // thresholds (nb_params.sym_tail) are taken as given.  Not below 1.5 rounds either: there the extra items of an early tail cost
+            // more than they balance (classic tiles, fp64 / 3-D handles at 16 384 ... 24 576 bodies: the late tail is 4-9 % faster;
+            // profiles/r04_small_n_plans_classic.log).
             double at[3] = {tune.tail_at[0], tune.tail_at[1], tune.tail_at[2]};
-            if (!tune.tail_given && world == 1 && !late_tail && (double)list.size() < 5.0 * 4.0 * (double)cus) { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }
+            if (!tune.tail_given && world == 1 && !late_tail && (double)list.size() >= 1.5 * 4.0 * (double)cus && (double)list.size() < 5.0 * 4.0 * (double)cus)
+                { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }
             std::vector<SymItem> out;
             out.reserve(list.size() * 2);
             for (const auto &it : list) {
