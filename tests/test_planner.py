@@ -173,3 +173,33 @@ def test_local_items_are_a_rank_independent_share():
         early, late = info["units_local"], info["units_late"]
         assert abs((early + late) / int(items["cnt"].sum()) - 1.0 / world) < 0.03
         assert (1200 <= late <= 1400 and late <= early) if world >= 8 else late == 0
+
+
+def test_small_system_plans_follow_the_measured_rules():
+    """Round 4's measurement-derived rules (planner bullet): whole-system wave-split plans use the finest uniform items
+    (one chunk per wave: 4 chunks per item) and NO guided tail while the item count stays within 25 per CU — their step is
+    9.1 + 7.3 x ceil(items / CUs) us, what counts is the count — then 8 chunks per item with the late tail up to the classic tiles'
+    size; classic plans start the tail early only between 1.5 and 5 rounds of workgroups."""
+    for n in (5632, 7168, 10000, 16384, 25000, 36000, 40000):
+        items, info = plan(n, 0, 1)
+        tiles = info["tiles"]
+        assert info["tile_particles"] == 512 and info["chunks_per_item"] == 4 and info["items"] <= 25 * 256
+        # uniform: every item holds 4 chunks except the one remainder per (tile, kind); the minimum possible count
+        assert int(np.sum(items["cnt"] < 4)) <= 2 * tiles and int(items["cnt"].max()) == 4
+        chunks = (n + CH - 1) // CH
+        want = sum(-(-(min((I + 1) * 8, chunks) - I * 8) // 4) + -(-(chunks - min((I + 1) * 8, chunks)) // 4) for I in range(tiles))
+        assert len(items) == want
+    for n in (41000, 49000):
+        items, info = plan(n, 0, 1)
+        assert info["tile_particles"] == 512 and info["chunks_per_item"] == 8
+        assert int(np.sum(items["cnt"] < 8)) > 4 * info["tiles"]                         # the late tail cut the end of the list finer
+    # an explicit item size or explicit thresholds are taken as given
+    items, info = plan(25000, 0, 1, sym_chunks_per_item=8)
+    assert info["chunks_per_item"] == 8
+    # classic tiles (fp64 handles): late tail below 1.5 rounds of workgroups, early tail between 1.5 and 5
+    p = dict(precision=L.NB_FP64)
+    late16, _ = plan(16384, 0, 1, **p)
+    early48, _ = plan(49152, 0, 1, **p)
+    forced_late = plan(49152, 0, 1, sym_tail=(C.c_float * 3)(0.85, 0.94, 0.98), **p)[0]
+    forced_early = plan(16384, 0, 1, sym_tail=(C.c_float * 3)(0.65, 0.85, 0.95), **p)[0]
+    assert len(late16) < len(forced_early) and len(early48) > len(forced_late)
