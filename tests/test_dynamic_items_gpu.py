@@ -32,7 +32,8 @@ def _same(a, b):
     (65536, 2, dict(precision="fp64")),
     (49152, 3, dict()),
     (32768, 3, dict(precision="fp64", uniform_mass=False)),
-    (8192, 2, dict()),                                               # one-sided kernel: no items, the flag is accepted and changes nothing
+    (8192, 2, dict()),                                               # 272 items on 1 024 slots: one wave, nothing is drawn
+    (4096, 2, dict()),                                               # one-sided kernel: no items, the flag is accepted and changes nothing
 ])
 def test_dynamic_items_leave_the_same_bits_as_static_ones(n, dims, kw):
     ic = nb.plummer_2d(n, 5) if dims == 2 else nb.plummer_3d(n, 5)
