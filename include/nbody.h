@@ -29,8 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is ALL it exports (`nm -D` shows exactly these
+ * nb_* symbols; tests/test_abi.py).  Test hooks live in include/nbody_debug.h and exist only in a -DNB_TEST_HOOKS build. */
+#pragma GCC visibility push(default)
 
-#define NB_ABI_VERSION 4
+#define NB_ABI_VERSION 5
 
 /* ---- particle record -------------------------------------------------------
  * Bit-compatible with the reference's `struct alignas(16) Body`
@@ -117,22 +120,9 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          acceleration of up to 6e-8 |x| m / eps^3 — 0.06 |x| m at eps = 0.01, growing as eps^-3 — and the
                                          total momentum is conserved to that level only, not to rounding (measured in
                                          tests/test_headline_gpu.py); one more reason the flag is opt-in */
-       NB_FLAG_PIPELINE        = 64,  /* EXPERIMENTAL, off by default: whole-system fp32 2-D handles run nb_step's whole loop as ONE persistent
-                                         launch (sym_pipeline_f32: in-order ticket queue, two per-tile counters where the launch boundaries
-                                         were, the last item to arrive at a tile gathers it) instead of two launches per step.  Same sums,
-                                         bit-identical results.  Level with two launches per step from 131 072 bodies up (+-1 %), SLOWER below
-                                         (+4 ... +23 %: every tile meets every tile in every step, so at most a quarter of a step separates a
-                                         tile's last pair from its first pair of the next step, and the tickets in flight plus one item's
-                                         duration exceed that at small N) */
-       NB_FLAG_ONE_LAUNCH_STEP = 128, /* EXPERIMENTAL, off by default: whole-system fp32 2-D kick-drift handles run a step as ONE launch (sym_step_f32:
-                                         the gather + kick + drift workgroups follow the force items in the same grid and wait, tile by tile, for
-                                         the items' arrivals; same sums, bit-identical results).  -1.1 ... -1.7 % per step at N = 49 152 ... 65 536,
-                                         -0.3 ... -0.6 % from 131 072 up, +0.5 ... +1.3 % below 49 152 (profiles/r04_one_launch_ab.log): what follows the last
-                                         force item — arrival, poll, acquire, gather — is as long as the launch boundary + gather launch it replaces.
-                                         Not the default because its progress argument rests on workgroups being dispatched in index order, which
-                                         HIP does not promise (a wait that does not end sets an error word within 4 s; the handle is then refused);
-                                         DESIGN.md 4.8.  Ignored where NB_FLAG_PIPELINE applies, and by handles that cannot step that way
-                                         (fp64, 3-D, KDK, sharded, one-sided: nb_describe says one_launch=0) */
+       /* 64 and 128 were NB_FLAG_PIPELINE / NB_FLAG_ONE_LAUNCH_STEP of ABI 4: two in-launch fusions of the step (a persistent step
+          pipeline, one launch per step) that measured level or slower than two launches per step (docs/rounds/r04.md) and were removed
+          in ABI 5 — nb_create rejects the bits like any unknown one */
        NB_FLAG_STATIC_ITEMS    = 256, /* the symmetric launches normally hand out their work items dynamically (every workgroup past the first
                                          resident wave draws the next item of the list when it starts, so that the XCDs of a part, which are not
                                          equally fast, end together: -1.4 ... -2.3 % per step from 65 536 bodies up, same bits); this bit keeps
@@ -427,21 +417,6 @@ int      nb_comm_phase_read(nb_comm *c, int handle, double *phase_ms /* NB_COMM_
  * still being replaced, is ignored — at most timeout_ms (NB_EIO after that).  Host-only (no GPU needed). */
 int      nb_comm_id_publish(const char *path, uint64_t nonce, const void *id /* NB_COMM_ID_BYTES */);
 int      nb_comm_id_await(const char *path, uint64_t nonce, void *id_out /* NB_COMM_ID_BYTES */, int timeout_ms);
-/* Test hook: load the nccl* entry points from `path` instead of librccl.so.1 (tests/loopback_rccl.hip: an in-process
- * transport that lets several ranks share one device, so nb_comm_step can run with 2 and 4 members on a one-GPU box).
- * Call before anything has loaded the transport; NULL restores the default. */
-int      nb_debug_comm_transport(const char *path);
-
-/* The schedule of ONE step as data: what nb_comm_step issues, in order (host-only view; the CPU tests check call order
- * and element counts with it).  kind: NB_OP_*; handle: index into the process's handle list (-1 for the group ops);
- * stream: 0 = the handle's compute stream, 1 = its communication stream; event: NB_EV_* (-1 if none);
- * count: elements (reals) of a collective — per rank for all-gather (send) and reduce-scatter (receive). */
-typedef struct nb_comm_op { int32_t kind, handle, stream, event; uint64_t count; } nb_comm_op;
-enum { NB_OP_BEGIN = 0, NB_OP_MID = 1, NB_OP_FINISH = 2, NB_OP_RECORD = 3, NB_OP_WAIT = 4, NB_OP_ALLGATHER = 5,
-       NB_OP_REDUCE_SCATTER = 6, NB_OP_ALLREDUCE = 7, NB_OP_GROUP_START = 8, NB_OP_GROUP_END = 9 };
-enum { NB_EV_POS = 0, NB_EV_AG = 1, NB_EV_ACC = 2, NB_EV_RED = 3 };
-int nb_debug_comm_schedule(int protocol, int handles, uint64_t block_reals, uint64_t full_reals, int ag_pending,
-                           nb_comm_op *ops_out, size_t cap, size_t *count);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* When enabled, every force-kernel launch is bracketed by HIP events on the
@@ -493,30 +468,6 @@ typedef struct nb_sym_info {
 } nb_sym_info;
 int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out);
 
-/* Host-only view of the planner (no GPU needed; used by the CPU tests to check that the items of all ranks
- * cover every unordered (tile, chunk) pair exactly once, that the slab ranges are disjoint, and the balance).
- * `tuning` may be NULL (defaults) — only flags, sym_chunks_per_item, sym_late_us, sym_tail and precision are read.
- * items_out receives up to cap items, local ones first, then cross, then late. */
-int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
-                      nb_sym_item *items_out, size_t cap, nb_sym_info *info);
-
-/* Debugging aid for the persistent step pipeline (whole-system fp32 2-D handles run nb_step's loop as ONE launch): with watch
- * on, every workgroup keeps a page-locked host word saying what it is doing (code << 56 | tile << 32 | ticket / step;
- * codes: 1 drew a ticket, 2 waits for a tile, 4 item body, 5 arrived, 6 left, 7 gathers a tile);
- * nb_debug_pipeline_state copies those words and the pipeline's device counters [queue head | done | ready] (2 x tiles after
- * the head) out while a launch is running. */
-int nb_debug_pipeline_watch(nb_sim *s, int on);
-int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t wg_cap, uint64_t *counters, size_t ctr_cap, uint32_t *tiles);
-
-/* Test hook for the dynamic work items (NB_FLAG_STATIC_ITEMS above): sets the handle's item-ticket counters, and the host's record of
- * what has been drawn, to `value` — a test steps a handle across the 2^32 wrap of the counters this way.  Waits for the handle's streams. */
-int nb_debug_ticket_seed(nb_sim *s, uint32_t value);
-
-/* Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) exactly as the device kernels evaluate it, on an array of n (even)
- * floats: y_scalar through the scalar form (reference-order kernel), y_packed through the packed form (tiled and
- * symmetric kernels).  Test hook for the bit-exact check against the reference's golden grid. */
-int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_packed, size_t n);
-
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int nb_device_count(void);
 
@@ -527,6 +478,7 @@ int nb_last_error_code(void);
 /* NB_ABI_VERSION the library was built with. */
 int nb_abi_version(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libnbody_hip.so"
 
-NB_ABI_VERSION = 4
+NB_ABI_VERSION = 5
 
 # enums (include/nbody.h)
 NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -29,8 +29,6 @@ NB_INTEGRATOR_KICK_DRIFT, NB_INTEGRATOR_KDK = 0, 1
 NB_POS_CURRENT, NB_POS_NEXT = 0, 1
 NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1, 2, 3
 NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE, NB_FLAG_SHARD_SINGLE, NB_FLAG_MASS_SCALING = 1, 2, 4, 8, 16, 32
-NB_FLAG_PIPELINE = 64
-NB_FLAG_ONE_LAUNCH_STEP = 128
 NB_FLAG_STATIC_ITEMS = 256
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
@@ -198,21 +196,14 @@ PROTOTYPES = {
     "nb_comm_phase_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "nb_comm_id_publish": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p]),
     "nb_comm_id_await": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p, C.c_int]),
-    "nb_debug_comm_transport": (C.c_int, [C.c_char_p]),
-    "nb_debug_comm_schedule": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "nb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nb_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "nb_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nb_plummer_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_plummer_3d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "nb_default_ics": (C.c_int, [C.c_void_p, C.c_size_t]),
-    "nb_debug_sym_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(nb_params), C.c_void_p, C.c_size_t, C.POINTER(nb_sym_info)]),
-    "nb_debug_ticket_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
-    "nb_debug_pipeline_watch": (C.c_int, [C.c_void_p, C.c_int]),
-    "nb_debug_pipeline_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "nb_sym_plan_info": (C.c_int, [C.c_void_p, C.POINTER(nb_sym_info)]),
     "nb_last_error_code": (C.c_int, []),
-    "nb_debug_fast_inv_sqrt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "nb_device_count": (C.c_int, []),
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),
@@ -221,62 +212,46 @@ PROTOTYPES = {
 _lib = None
 
 
-def load() -> C.CDLL:
-    """Load the product library; raise if it is missing or its ABI differs."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = Path(os.environ.get("NBODY_HIP_LIB", LIB_PATH))
+def bind(path, prototypes=None) -> C.CDLL:
+    """Load a build of the library from ``path`` and declare ``prototypes`` (default: the product ABI) on it; raises if the
+    file is missing, lacks a declared symbol, or was built for another ABI version.  ``load()`` is this for the product
+    library; the tests bind their -DNB_TEST_HOOKS build (tests/hooks.py) the same way."""
+    path = Path(path)
     if not path.exists():
         raise ImportError(
             f"{path} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C nbodysim_amd/csrc` (there is no CPU fallback)"
         )
     lib = C.CDLL(str(path))
-    for name, (restype, argtypes) in PROTOTYPES.items():
+    for name, (restype, argtypes) in (PROTOTYPES if prototypes is None else prototypes).items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.nb_abi_version() != NB_ABI_VERSION:
         raise ImportError(f"{path}: ABI version {lib.nb_abi_version()} != binding {NB_ABI_VERSION}")
-    _lib = lib
     return lib
 
 
-def last_error() -> str:
-    return (load().nb_last_error() or b"").decode("utf-8", "replace")
+def load() -> C.CDLL:
+    """Load the product library; raise if it is missing or its ABI differs."""
+    global _lib
+    if _lib is None:
+        _lib = bind(os.environ.get("NBODY_HIP_LIB", LIB_PATH))
+    return _lib
 
 
-def last_error_code() -> int:
-    return int(load().nb_last_error_code())
+def last_error(lib=None) -> str:
+    return ((lib or load()).nb_last_error() or b"").decode("utf-8", "replace")
 
 
-def sym_plan(n: int, cus: int = 256, rank: int = 0, world: int = 1, tuning: "nb_params | None" = None):
-    """Host-only planner view: (items as a SYM_ITEM_DTYPE array, info dict).  No GPU needed."""
-    lib = load()
-    info = nb_sym_info()
-    info.struct_size = C.sizeof(nb_sym_info)
-    tp = C.byref(tuning) if tuning is not None else None
-    check("nb_debug_sym_plan", lib.nb_debug_sym_plan(n, cus, rank, world, tp, None, 0, C.byref(info)))
-    items = np.zeros(info.items, SYM_ITEM_DTYPE)
-    check("nb_debug_sym_plan", lib.nb_debug_sym_plan(n, cus, rank, world, tp, items.ctypes.data, info.items, C.byref(info)))
-    return items, info.as_dict()
+def last_error_code(lib=None) -> int:
+    return int((lib or load()).nb_last_error_code())
 
 
-def comm_schedule(protocol: int, handles: int, block_reals: int, full_reals: int, ag_pending: bool) -> np.ndarray:
-    """Host-only: the operations ``nb_comm_step`` issues for one step (``nb_debug_comm_schedule``), as a COMM_OP_DTYPE array."""
-    lib = load()
-    cnt = C.c_size_t()
-    check("nb_debug_comm_schedule", lib.nb_debug_comm_schedule(protocol, handles, block_reals, full_reals, int(ag_pending), None, 0, C.byref(cnt)))
-    ops = np.zeros(cnt.value, COMM_OP_DTYPE)
-    check("nb_debug_comm_schedule", lib.nb_debug_comm_schedule(protocol, handles, block_reals, full_reals, int(ag_pending),
-                                                               ops.ctypes.data, cnt.value, C.byref(cnt)))
-    return ops
-
-
-def check(where: str, rc: int) -> None:
+def check(where: str, rc: int, lib=None) -> None:
+    """Raise ``NBodyError`` for a non-zero status; ``lib`` = the build the call went to (its thread-local error text)."""
     if rc != NB_OK:
-        raise NBodyError(where, rc, last_error())
+        raise NBodyError(where, rc, last_error(lib))
 
 
 def default_params() -> nb_params:

@@ -48,47 +48,47 @@ class Comm:
     ``Comm.rank(sim, id, rank, world)``: one process per GPU."""
 
     def __init__(self, handle: int, sims: Sequence):
-        self._lib = L.load()
+        self._lib = sims[0]._lib          # the build the handles came from (the product, or the tests' hooks build)
         self._h = handle
         self.sims = list(sims)            # keep the handles alive as long as the communicator
 
     @classmethod
     def all(cls, sims: Sequence) -> "Comm":
-        lib = L.load()
+        lib = sims[0]._lib
         arr = (C.c_void_p * len(sims))(*[s._h for s in sims])
         h = lib.nb_comm_create_all(arr, len(sims))
         if not h:
-            raise L.NBodyError("nb_comm_create_all", L.last_error_code(), L.last_error())
+            raise L.NBodyError("nb_comm_create_all", L.last_error_code(lib), L.last_error(lib))
         return cls(h, sims)
 
     @classmethod
     def rank(cls, sim, uid: bytes, rank: int, world: int) -> "Comm":
         if len(uid) != L.NB_COMM_ID_BYTES:
             raise ValueError("uid must be the NB_COMM_ID_BYTES bytes of nb_comm_unique_id")
-        h = L.load().nb_comm_create_rank(sim._h, uid, rank, world)
+        h = sim._lib.nb_comm_create_rank(sim._h, uid, rank, world)
         if not h:
-            raise L.NBodyError("nb_comm_create_rank", L.last_error_code(), L.last_error())
+            raise L.NBodyError("nb_comm_create_rank", L.last_error_code(sim._lib), L.last_error(sim._lib))
         return cls(h, [sim])
 
     def step(self, nsteps: int = 1, dt: Optional[float] = None) -> None:
         """Enqueue ``nsteps`` sharded steps; returns as soon as they are enqueued."""
-        L.check("nb_comm_step", self._lib.nb_comm_step(self._h, 0.0 if dt is None else dt, nsteps))
+        L.check("nb_comm_step", self._lib.nb_comm_step(self._h, 0.0 if dt is None else dt, nsteps), self._lib)
 
     def flush(self) -> None:
-        L.check("nb_comm_flush", self._lib.nb_comm_flush(self._h))
+        L.check("nb_comm_flush", self._lib.nb_comm_flush(self._h), self._lib)
 
     def wait(self) -> None:
-        L.check("nb_comm_wait", self._lib.nb_comm_wait(self._h))
+        L.check("nb_comm_wait", self._lib.nb_comm_wait(self._h), self._lib)
 
     def profile(self, on: bool = True) -> None:
         """Per-phase HIP events inside the library's loop (``nb_comm_profile``); off by default."""
-        L.check("nb_comm_profile", self._lib.nb_comm_profile(self._h, int(on)))
+        L.check("nb_comm_profile", self._lib.nb_comm_profile(self._h, int(on)), self._lib)
 
     def phases(self, handle: int = 0, reset: bool = True) -> dict:
         """``nb_comm_phase_read``: {phase: mean ms per step on the compute stream, ..., "steps": k} for local handle ``handle``."""
         ms = (C.c_double * L.NB_COMM_PHASES)()
         steps = C.c_uint64()
-        L.check("nb_comm_phase_read", self._lib.nb_comm_phase_read(self._h, handle, ms, C.byref(steps), int(reset)))
+        L.check("nb_comm_phase_read", self._lib.nb_comm_phase_read(self._h, handle, ms, C.byref(steps), int(reset)), self._lib)
         k = max(1, int(steps.value))
         out = {name: ms[i] / k for i, name in enumerate(L.NB_PH_NAMES)}
         out["steps"] = int(steps.value)
@@ -96,7 +96,7 @@ class Comm:
 
     def info(self) -> dict:
         p, w, k, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        L.check("nb_comm_info", self._lib.nb_comm_info(self._h, C.byref(p), C.byref(w), C.byref(k), C.byref(v)))
+        L.check("nb_comm_info", self._lib.nb_comm_info(self._h, C.byref(p), C.byref(w), C.byref(k), C.byref(v)), self._lib)
         return {"protocol": p.value, "world": w.value, "local_handles": k.value, "rccl_version": v.value}
 
     def close(self) -> None:

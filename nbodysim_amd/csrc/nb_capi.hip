@@ -7,6 +7,7 @@
 //   vel,acc  owned block only  partial [slabs][i_count] force partial sums
 // No CPU fallback exists: every entry that computes needs a HIP device.
 #include "nbody.h"
+#include "nbody_debug.h"
 #include "nb_internal.h"
 #include "nb_kernels.hip.h"
 #include "nb_kernels3d.hip.h"
@@ -110,26 +111,11 @@ struct nb_sim {
     SymCov *sym_cov_dev = nullptr;             // coverage entries: main lists, then (from sym_cov_late_off) the late ones
     nb_sym_info sym_info{};
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
-    // persistent step pipeline (sym_pipeline_f32): nb_step(dt, nsteps) of a whole-system fp32 2-D handle is ONE launch
-    bool pipe = false;                         // the handle's plan can run it (decided in plan_sym)
-    bool pipe_failed = false;                  // a launch gave up (time-out word set): the counters are inconsistent, the handle is refused
-    u64_t *pipe_ctr = nullptr;                 // device: [head | done | ready] (tiles counters each after the head), one 128-byte line per counter
-    uint32_t *pipe_expected_dev = nullptr;     // device: items touching each tile
-    uint32_t *pipe_order_dev = nullptr;        // device: ticket -> item (the anti-diagonal order of the pipeline)
-    int *pipe_err = nullptr;                   // page-locked host word the kernels set when a wait does not end
-    u64_t pipe_epoch = 0, pipe_tickets = 0;    // steps / tickets the pipeline has completed so far (its counters are monotonic)
-    uint32_t pipe_grid = 0;                    // resident workgroups of the variant this handle launches
-    u64_t *pipe_dbg = nullptr;                 // nb_debug_pipeline_watch: page-locked host words, one per workgroup
     // dynamic item tickets of the whole-system symmetric launch (sym_item_index, nb_kernels.hip.h)
     uint32_t *sym_ticket = nullptr;            // device: one counter on a line of its own, monotonic modulo 2^32
     uint32_t sym_ticket_base[3] = {0, 0, 0};   // what the launches so far have drawn, per launch kind (local or whole | cross | late: one counter each,
                                                // 128 bytes apart — a sharded rank's launches may run side by side)
     uint32_t sym_first_wave = 0;               // workgroups that keep their static item (the resident slots of the kernel variant); 0 = not yet known
-    // one launch per step (sym_step_f32): the gather + kick + drift ride in the drain of the force launch
-    bool fused = false;                        // the handle steps that way (decided in plan_sym; opt-in NB_FLAG_ONE_LAUNCH_STEP)
-    uint32_t *step_done = nullptr;             // device: per-tile arrivals, monotonic modulo 2^32
-    uint32_t step_epoch = 0;                   // fused launches so far (modulo 2^32, like the counters)
-    hipStream_t dbg_stream = nullptr;
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
     // symmetric REPLICATED protocol (NB_FLAG_SHARD_ALLREDUCE): the handle holds this rank's share of the pairs like a
@@ -372,6 +358,7 @@ static void fill_sym_info(const SymPlan &pl, uint32_t n, uint32_t world, int cus
     out->coverage_entries = pl.cov_main.size() + pl.cov_late.size();
 }
 
+#ifdef NB_TEST_HOOKS   /* include/nbody_debug.h: test build only */
 // CPU-testable view of the planner (no device call).
 extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const nb_params *tuning,
                                  nb_sym_item *items_out, size_t cap, nb_sym_info *info)
@@ -392,6 +379,7 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
     if (items_out) memcpy(items_out, pl.items.data(), (pl.items.size() < cap ? pl.items.size() : cap) * sizeof(SymItem));
     return NB_OK;
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // host memory
@@ -552,57 +540,8 @@ static int plan_sym(nb_sim *s)
     if ((rc = copy_h2d(s, s->sym_rowbase_dev, bounds.data(), bounds.size() * sizeof(uint32_t)))) return rc;
     if ((rc = copy_h2d(s, s->sym_cov_begin_dev, cbegin.data(), cbegin.size() * sizeof(uint32_t)))) return rc;
     if ((rc = copy_h2d(s, s->sym_cov_dev, cov.data(), cov.size() * sizeof(SymCov)))) return rc;
-    // Persistent step pipeline (nb_kernels.hip.h: sym_pipeline_f32; EXPERIMENTAL, opt-in NB_FLAG_PIPELINE): whole-system fp32 2-D handles.  expected[g] = items
-    // that touch tile g (their stationary tile, or a tile their travelling chunks lie in); an item's tiles must fit the
-    // kernel's 32-bit "I was last" mask (1 + 31 tiles: any plan the planner sizes itself, not every forced one).
     HIPCHK(hipMalloc((void **)&s->sym_ticket, 3 * 128));
     HIPCHK(hipMemsetAsync(s->sym_ticket, 0, 3 * 128, s->stream));
-    s->pipe = false;
-    s->fused = false;
-    const bool whole_f32 = s->sym && !split && !s->fp64 && !s->dims3 && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT;
-    const bool want_pipe = whole_f32 && (s->p.flags & NB_FLAG_PIPELINE);
-    const bool want_fused = whole_f32 && !want_pipe && (s->p.flags & NB_FLAG_ONE_LAUNCH_STEP);
-    if (want_pipe || want_fused) {
-        const uint32_t shift = pl.sb == SYM_SB_WS ? 9u : 11u;
-        std::vector<uint32_t> expected(tiles, 0u);
-        uint32_t span = 0;
-        for (const SymItem &it : pl.items) {
-            ++expected[it.tile];
-            if (it.diag) continue;
-            const uint64_t end = (uint64_t)(it.c0 + it.cnt) * SYM_CH;
-            const uint32_t lastp = (uint32_t)(end < n ? end : n) - 1u, t_lo = (it.c0 * SYM_CH) >> shift, t_hi = lastp >> shift;
-            for (uint32_t g = t_lo; g <= t_hi; ++g) ++expected[g];
-            if (t_hi - t_lo + 1u > span) span = t_hi - t_lo + 1u;
-        }
-        HIPCHK(hipMalloc((void **)&s->pipe_expected_dev, tiles * sizeof(uint32_t)));
-        if ((rc = copy_h2d(s, s->pipe_expected_dev, expected.data(), tiles * sizeof(uint32_t)))) return rc;
-        HIPCHK(hipHostMalloc((void **)&s->pipe_err, sizeof(int), hipHostMallocDefault));
-        *s->pipe_err = 0;
-        if (want_fused) {
-            // One launch per step (sym_step_f32): per-tile arrival counters, zero at epoch 0.
-            HIPCHK(hipMalloc((void **)&s->step_done, (size_t)tiles * STEP_CTR_STRIDE * sizeof(uint32_t)));
-            HIPCHK(hipMemsetAsync(s->step_done, 0, (size_t)tiles * STEP_CTR_STRIDE * sizeof(uint32_t), s->stream));
-            s->step_epoch = 0;
-            s->fused = true;
-        } else if (span <= 31u) {
-            // PIPE ORDER.  Tile-major order (tile I against every later chunk, I ascending) is what one launch per step wants, but
-            // in a pipeline the first items of the next step — tile 0 against EVERY tile — would need every tile of this step
-            // finished.  Tickets are therefore drawn along the ANTI-DIAGONALS of the (tile, chunk-tile) triangle, s = I + t
-            // ascending: tile g's pairs then span s in [g, g + tiles) of [0, 2 tiles), i.e. at most 3/4 of a step from its
-            // first to its last pair, so with the same order every step a quarter of the next step can run beside the end
-            // of this one — the room the hand-off at a step's end (last arrivals, gathers, first loads) needs.
-            std::vector<uint32_t> order(pl.items.size());
-            for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-            auto key = [&](uint32_t i) { const SymItem &it = pl.items[i]; return it.tile + (it.diag ? it.tile : (it.c0 * SYM_CH) >> shift); };
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-            HIPCHK(hipMalloc((void **)&s->pipe_order_dev, order.size() * sizeof(uint32_t)));
-            if ((rc = copy_h2d(s, s->pipe_order_dev, order.data(), order.size() * sizeof(uint32_t)))) return rc;
-            const size_t words = (1 + 2 * (size_t)tiles) * PIPE_CTR_STRIDE;     // [head | done | ready], one 128-byte line per counter
-            HIPCHK(hipMalloc((void **)&s->pipe_ctr, words * sizeof(u64_t)));
-            HIPCHK(hipMemsetAsync(s->pipe_ctr, 0, words * sizeof(u64_t), s->stream));
-            s->pipe = true;
-        }
-    }
     // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
     // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
     // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
@@ -638,10 +577,7 @@ static void free_all(nb_sim *s)
     (void)hipFree(s->sym_items_dev); (void)hipFree(s->sym_rowbase_dev); (void)hipFree(s->sym_cov_begin_dev); (void)hipFree(s->sym_cov_dev);
     if (s->own_acc) { (void)hipFree(s->acc_full); (void)hipFree(s->acc_owned); }
     (void)hipFree(s->sym_slab_s); (void)hipFree(s->sym_slab_r);
-    (void)hipFree(s->pipe_ctr); (void)hipFree(s->pipe_expected_dev); (void)hipFree(s->pipe_order_dev); (void)hipFree(s->step_done); (void)hipFree(s->sym_ticket);
-    if (s->pipe_err) (void)hipHostFree(s->pipe_err);
-    if (s->pipe_dbg) (void)hipHostFree(s->pipe_dbg);
-    if (s->dbg_stream) (void)hipStreamDestroy(s->dbg_stream);
+    (void)hipFree(s->sym_ticket);
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
     if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
@@ -735,7 +671,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_PIPELINE | NB_FLAG_ONE_LAUNCH_STEP | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
@@ -1096,67 +1032,6 @@ static int launch_sym_gather_late(nb_sim *s, double dt)
     return NB_OK;
 }
 
-// One step of a whole-system fp32 2-D handle as ONE launch (sym_step_f32): the force items, then — in the slots the last
-// items leave free — the gather workgroups, each waiting for its tile's arrivals.  Same items, slabs and sums as
-// launch_sym_items + launch_sym_gather(fuse_step): bit-identical results.
-static int launch_sym_step(nb_sim *s, float dt)
-{
-    if (s->pipe_failed) return nb_fail(NB_ESTATE, "nb_step: an earlier launch gave up (a device-side wait timed out); the handle cannot continue");
-    StepArgs a;
-    memset(&a, 0, sizeof a);
-    a.pos_cur = (const float2 *)s->pos[s->cur]; a.pos_next = (float2 *)s->pos[s->cur ^ 1];
-    a.mass = (const float *)s->mass; a.sigma = s->sigma;
-    a.items = s->sym_items_dev;
-    a.slab_s = (float2 *)s->sym_slab_s; a.slab_r = (float2 *)s->sym_slab_r;
-    a.row_lo = s->sym_rowbase_dev; a.row_hi = s->sym_rowbase_dev + s->sym_tiles;      // no late rows in a whole-system plan
-    a.cov_begin = s->sym_cov_begin_dev; a.cov = s->sym_cov_dev;
-    a.expected = s->pipe_expected_dev; a.done = s->step_done; a.err = s->pipe_err;
-    a.vel = (float2 *)s->vel; a.acc = (float2 *)s->acc;
-    a.n = (uint32_t)s->n; a.n_items = s->sym_items; a.sb_shift = s->sym_sb_shift;
-    a.epoch = ++s->step_epoch;
-    a.eps2 = s->p.eps * s->p.eps; a.um_mass = s->uniform_mass ? s->um_mass : 1.0f; a.dt = dt; a.extras = s->p.extras;
-    const uint32_t grid = s->sym_items + (a.n + (uint32_t)GATHER_P - 1u) / (uint32_t)GATHER_P;
-    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE, ws = s->sym_sb == SYM_SB_WS;
-    const bool pairs = s->sym_pairs && !s->mass_scaled;
-    std::pair<hipEvent_t, hipEvent_t> pr;
-    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
-    // the force part draws its items from the handle's whole-system counter (slot 0), like launch_sym_items
-    const bool dyn = s->sym_ticket != nullptr && !(s->p.flags & NB_FLAG_STATIC_ITEMS);
-#define NB_STEP_ONE(KERNEL)                                                                                          \
-    do {                                                                                                             \
-        if (dyn) {                                                                                                   \
-            if (!s->sym_first_wave) {                                                                                \
-                int per_cu = 0;                                                                                      \
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, BLOCK, 0));                     \
-                s->sym_first_wave = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)s->cus;                          \
-            }                                                                                                        \
-            a.first_wave = s->sym_first_wave < s->sym_items ? s->sym_first_wave : s->sym_items;                      \
-            a.ticket = s->sym_ticket; a.ticket_base = s->sym_ticket_base[0];                                         \
-            s->sym_ticket_base[0] += s->sym_items - a.first_wave;                                                    \
-        }                                                                                                            \
-        KERNEL<<<grid, BLOCK, 0, s->stream>>>(a);                                                                    \
-    } while (0)
-#define NB_STEP_GO(RQ, MMODE, PR)                                                                                   \
-    do {                                                                                                             \
-        if (ws) NB_STEP_ONE((sym_step_f32<RQ, MMODE, PR, true>));                                                    \
-        else    NB_STEP_ONE((sym_step_f32<RQ, MMODE, PR, false>));                                                   \
-    } while (0)
-    if (s->uniform_mass) {
-        if (quake) { if (pairs) NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, true); else NB_STEP_GO(RSQ_QUAKE, MM_UNIFORM, false); }
-        else       { if (pairs) NB_STEP_GO(RSQ_EXACT, MM_UNIFORM, true); else NB_STEP_GO(RSQ_EXACT, MM_UNIFORM, false); }
-    } else if (s->mass_scaled) {
-        NB_STEP_GO(RSQ_EXACT, MM_SCALED, false);
-    } else {
-        if (quake) { if (pairs) NB_STEP_GO(RSQ_QUAKE, MM_GENERAL, true); else NB_STEP_GO(RSQ_QUAKE, MM_GENERAL, false); }
-        else       { if (pairs) NB_STEP_GO(RSQ_EXACT, MM_GENERAL, true); else NB_STEP_GO(RSQ_EXACT, MM_GENERAL, false); }
-    }
-#undef NB_STEP_GO
-#undef NB_STEP_ONE
-    HIPCHK(hipGetLastError());
-    if (s->prof && prof_end(s, pr)) return NB_EHIP;
-    return NB_OK;
-}
-
 // Whole-system symmetric force (+ optionally the kick/drift).
 static int launch_force_sym(nb_sim *s, bool fuse_step = false, double dt = 0.0)
 {
@@ -1401,9 +1276,8 @@ extern "C" int nb_step_finish(nb_sim *s)
         return NB_OK;
     }
     if (s->sym && s->p.integrator == NB_INTEGRATOR_KICK_DRIFT) {
-        // whole system, symmetric kernel: the gather applies the kick and the drift itself — inside the force launch where the
-        // handle can (sym_step_f32), as a second launch otherwise
-        if ((rc = s->fused ? launch_sym_step(s, s->pending_dt) : launch_force_sym(s, true, (double)s->pending_dt))) return rc;
+        // whole system, symmetric kernel: the gather launch applies the kick and the drift itself
+        if ((rc = launch_force_sym(s, true, (double)s->pending_dt))) return rc;
         s->cur ^= 1;
         s->frame += 1;
         s->acc_valid = false;
@@ -1421,87 +1295,6 @@ extern "C" int nb_step_finish(nb_sim *s)
     s->cur ^= 1;
     s->frame += 1;                                  // Simulation.hpp:74
     s->acc_valid = false;
-    return NB_OK;
-}
-
-constexpr size_t PIPE_DBG_WORDS = 4096;       // nb_debug_pipeline_watch: one host word per workgroup
-
-// nsteps steps of a whole-system handle as ONE persistent launch (sym_pipeline_f32).  The same items, the same slabs, the
-// same sums as launch_force_sym(fuse_step) step by step — bit-identical results — without the two launch boundaries,
-// the fill and the drain of every step.
-static int launch_pipeline(nb_sim *s, float dt, int nsteps)
-{
-    if (s->pipe_failed) return nb_fail(NB_ESTATE, "nb_step: an earlier pipeline launch gave up (a device-side wait timed out); the handle cannot continue");
-    PipeArgs a;
-    memset(&a, 0, sizeof a);
-    a.pos[0] = (const float2 *)s->pos[0]; a.pos[1] = (const float2 *)s->pos[1];
-    a.pos_w[0] = (float2 *)s->pos[0]; a.pos_w[1] = (float2 *)s->pos[1];
-    a.mass = (const float *)s->mass; a.sigma = s->sigma;
-    a.items = s->sym_items_dev;
-    a.order = s->pipe_order_dev;
-    a.slab_s = (float2 *)s->sym_slab_s; a.slab_r = (float2 *)s->sym_slab_r;
-    a.row_lo = s->sym_rowbase_dev; a.row_hi = s->sym_rowbase_dev + s->sym_tiles;      // no late rows in a whole-system plan
-    a.cov_begin = s->sym_cov_begin_dev; a.cov = s->sym_cov_dev;
-    a.expected = s->pipe_expected_dev;
-    a.vel = (float2 *)s->vel; a.acc = (float2 *)s->acc;
-    const size_t per = (size_t)s->sym_tiles * PIPE_CTR_STRIDE;
-    a.head = s->pipe_ctr; a.done = s->pipe_ctr + PIPE_CTR_STRIDE; a.ready = a.done + per;
-    a.err = s->pipe_err;
-    a.dbg = s->pipe_dbg;
-    a.n = (uint32_t)s->n; a.n_items = s->sym_items; a.tiles = s->sym_tiles; a.sb_shift = s->sym_sb_shift;
-    a.steps = (uint32_t)nsteps; a.cur0 = (uint32_t)s->cur;
-    a.epoch0 = s->pipe_epoch; a.ticket0 = s->pipe_tickets;
-    a.eps2 = s->p.eps * s->p.eps; a.um_mass = s->uniform_mass ? s->um_mass : 1.0f; a.dt = dt; a.extras = s->p.extras;
-    const bool quake = s->p.rsqrt_mode == NB_RSQRT_QUAKE, ws = s->sym_sb == SYM_SB_WS;
-    const bool pairs = s->sym_pairs && !s->mass_scaled;
-    const uint64_t tickets = (uint64_t)nsteps * s->sym_items;
-    uint32_t grid = 0;
-    std::pair<hipEvent_t, hipEvent_t> pr;
-    if (s->prof && prof_begin(s, &pr)) return NB_EHIP;
-    // resident workgroups: the occupancy the variant gets on this device (a surplus would only start once the queue is
-    // empty and leave at once; workgroups that hold no ticket are never waited for)
-#define NB_PIPE_GO(RQ, MMODE, PR, WSV)                                                                                         \
-    do {                                                                                                                        \
-        if (!s->pipe_grid) {                                                                                                    \
-            int per_cu = 0;                                                                                                     \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_pipeline_f32<RQ, MMODE, PR, WSV>, BLOCK, 0));      \
-            s->pipe_grid = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)s->cus;                                              \
-        }                                                                                                                       \
-        grid = tickets < s->pipe_grid ? (uint32_t)tickets : s->pipe_grid;                                                       \
-        if (s->pipe_dbg && grid > PIPE_DBG_WORDS) grid = (uint32_t)PIPE_DBG_WORDS;                                              \
-        sym_pipeline_f32<RQ, MMODE, PR, WSV><<<grid, BLOCK, 0, s->stream>>>(a);                                                 \
-    } while (0)
-#define NB_PIPE_WS(RQ, MMODE, PR) do { if (ws) NB_PIPE_GO(RQ, MMODE, PR, true); else NB_PIPE_GO(RQ, MMODE, PR, false); } while (0)
-    if (s->uniform_mass) {
-        if (quake) { if (pairs) NB_PIPE_WS(RSQ_QUAKE, MM_UNIFORM, true); else NB_PIPE_WS(RSQ_QUAKE, MM_UNIFORM, false); }
-        else       { if (pairs) NB_PIPE_WS(RSQ_EXACT, MM_UNIFORM, true); else NB_PIPE_WS(RSQ_EXACT, MM_UNIFORM, false); }
-    } else if (s->mass_scaled) {
-        NB_PIPE_WS(RSQ_EXACT, MM_SCALED, false);
-    } else {
-        if (quake) { if (pairs) NB_PIPE_WS(RSQ_QUAKE, MM_GENERAL, true); else NB_PIPE_WS(RSQ_QUAKE, MM_GENERAL, false); }
-        else       { if (pairs) NB_PIPE_WS(RSQ_EXACT, MM_GENERAL, true); else NB_PIPE_WS(RSQ_EXACT, MM_GENERAL, false); }
-    }
-#undef NB_PIPE_WS
-#undef NB_PIPE_GO
-    HIPCHK(hipGetLastError());
-    if (s->prof && prof_end(s, pr, nullptr, (uint32_t)nsteps)) return NB_EHIP;
-    s->pipe_epoch += (uint64_t)nsteps;
-    s->pipe_tickets += tickets + grid;      // every workgroup leaves by drawing ONE ticket past the end: the queue head stands there
-    s->cur ^= nsteps & 1;
-    s->frame += (uint64_t)nsteps;
-    s->acc_valid = false;
-    return NB_OK;
-}
-
-// after the stream has been synchronised: did a pipeline launch give up?
-static int pipe_check(nb_sim *s)
-{
-    if (s->pipe_err && *(volatile int *)s->pipe_err != 0) {
-        s->pipe_failed = true;
-        return nb_fail(NB_EHIP, "a step launch gave up (code %d: 1 = a device-side wait for a tile did not end within %.0f s, 2 / 3 = a bounded "
-                                "loop ran out): this is a bug in the library, not a legal state; the handle's state is undefined",
-                       *(volatile int *)s->pipe_err, (double)PIPE_TIMEOUT_TICKS * 1e-8);
-    }
     return NB_OK;
 }
 
@@ -1533,16 +1326,6 @@ extern "C" int nb_step(nb_sim *s, float dt, int nsteps)
     if (s->in_step) return nb_fail(NB_ESTATE, "nb_step: a split step is in flight");
     if (bind(s)) return NB_EHIP;
     const float h = dt > 0.0f ? dt : s->p.dt;
-    if (s->pipe && nsteps > 0) {
-        // one persistent launch per 4096 steps (bounds a launch's duration; the tickets stay far inside 64 bits)
-        for (int done = 0; done < nsteps;) {
-            const int batch = nsteps - done < 4096 ? nsteps - done : 4096;
-            const int rc = launch_pipeline(s, h, batch);
-            if (rc) return rc;
-            done += batch;
-        }
-        return NB_OK;
-    }
     for (int k = 0; k < nsteps; ++k) {
         int rc;
         if (s->p.integrator == NB_INTEGRATOR_KDK) { if ((rc = step_kdk(s, h))) return rc; continue; }
@@ -1570,7 +1353,7 @@ extern "C" int nb_wait(nb_sim *s)
     if (bind(s)) return NB_EHIP;
     if (s->aux) HIPCHK(hipStreamSynchronize(s->aux));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return pipe_check(s);
+    return NB_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1714,7 +1497,7 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
     // registered destination: one DMA; pageable destination: staged in pieces, the host copies piece k out while
     // piece k + 1 is still in flight
     if ((rc = copy_d2h(s, out, s->aos_dev, bytes, s->stream, direct ? nullptr : s->staging))) return rc;
-    return pipe_check(s);                             // the copy waited for the stream: did a pipeline launch give up?
+    return NB_OK;
 }
 
 extern "C" int nb_sync_positions(nb_sim *s, float *out_xy)
@@ -1982,6 +1765,7 @@ extern "C" int nb_profile_read(nb_sim *s, double *force_ms_total, uint64_t *forc
     return NB_OK;
 }
 
+#ifdef NB_TEST_HOOKS   /* include/nbody_debug.h: test build only */
 // Quadtree::fast_inv_sqrt (Quadtree.hpp:106-111) as the device evaluates it, on an array: y_scalar from the scalar form
 // used by the sequential kernel, y_packed from the packed form of the tiled / symmetric kernels.  n must be even.
 extern "C" int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_packed, size_t n)
@@ -2012,40 +1796,6 @@ extern "C" int nb_debug_fast_inv_sqrt(const float *x, float *y_scalar, float *y_
     return rc;
 }
 
-// Debugging aid for the persistent step pipeline: with watch on, every workgroup of a launch keeps one page-locked host word
-// up to date with what it is doing (nb_kernels.hip.h: pipe_dbg); nb_debug_pipeline_state copies those words and the
-// pipeline's device counters [head | done | ready] out WHILE a launch is running (own stream).
-extern "C" int nb_debug_pipeline_watch(nb_sim *s, int on)
-{
-    if (!s) return nb_fail(NB_EINVAL, "nb_debug_pipeline_watch: NULL handle");
-    if (!s->pipe) return nb_fail(NB_ESTATE, "nb_debug_pipeline_watch: the handle does not run the step pipeline");
-    if (bind(s)) return NB_EHIP;
-    if (on && !s->pipe_dbg) {
-        HIPCHK(hipHostMalloc((void **)&s->pipe_dbg, PIPE_DBG_WORDS * sizeof(u64_t), hipHostMallocDefault));
-        memset(s->pipe_dbg, 0, PIPE_DBG_WORDS * sizeof(u64_t));
-        HIPCHK(hipStreamCreateWithFlags(&s->dbg_stream, hipStreamNonBlocking));
-    }
-    if (!on && s->pipe_dbg) { HIPCHK(hipStreamSynchronize(s->stream)); (void)hipHostFree(s->pipe_dbg); s->pipe_dbg = nullptr; }
-    return NB_OK;
-}
-
-extern "C" int nb_debug_pipeline_state(nb_sim *s, uint64_t *workgroups, size_t wg_cap, uint64_t *counters, size_t ctr_cap, uint32_t *tiles)
-{
-    if (!s || !s->pipe) return nb_fail(NB_EINVAL, "nb_debug_pipeline_state: no pipeline");
-    if (tiles) *tiles = s->sym_tiles;
-    if (workgroups && s->pipe_dbg) memcpy(workgroups, s->pipe_dbg, (wg_cap < PIPE_DBG_WORDS ? wg_cap : PIPE_DBG_WORDS) * sizeof(uint64_t));
-    if (counters && s->dbg_stream) {
-        // the caller's view is compact ([head | done | ready], tiles words each); on the device every counter has a line of its own
-        const size_t words = 1 + 2 * (size_t)s->sym_tiles, k = ctr_cap < words ? ctr_cap : words;
-        if (bind(s)) return NB_EHIP;
-        std::vector<uint64_t> raw(words * PIPE_CTR_STRIDE);
-        HIPCHK(hipMemcpyAsync(raw.data(), s->pipe_ctr, raw.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s->dbg_stream));
-        HIPCHK(hipStreamSynchronize(s->dbg_stream));
-        for (size_t i = 0; i < k; ++i) counters[i] = raw[i * PIPE_CTR_STRIDE];
-    }
-    return NB_OK;
-}
-
 // Test hook: move the handle's item-ticket counters (device) and the host's record of them to `value`, as if the launches so far
 // had drawn that many items — so that a test can step a handle ACROSS the 2^32 wrap of the counters (580 000 steps away at
 // N = 262 144) in a few steps.
@@ -2062,6 +1812,7 @@ extern "C" int nb_debug_ticket_seed(nb_sim *s, uint32_t value)
     HIPCHK(hipMemcpy(s->sym_ticket, words, sizeof words, hipMemcpyHostToDevice));
     return NB_OK;
 }
+#endif
 
 extern "C" int nb_sym_plan_info(const nb_sim *s, nb_sym_info *out)
 {
@@ -2079,13 +1830,13 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d pipeline=%d one_launch=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
              s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
-             (int)(s->sym || s->sym_sharded || s->sym_replicated), (int)s->pipe, (int)s->fused, s->sym_sb,
+             (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_sb,
              (int)(s->sym_pairs && !s->mass_scaled && (!s->dims3 || s->uniform_mass || s->p.sym_chunk_pairs > 0)), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);
     return NB_OK;

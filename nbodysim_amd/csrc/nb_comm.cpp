@@ -29,6 +29,7 @@
 #include "nb_internal.h"
 #include "nb_sched.h"
 #include "nbody.h"
+#include "nbody_debug.h"
 
 using namespace nbk;
 
@@ -53,7 +54,9 @@ struct Rccl {
 
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
-std::string g_transport_path;                             // nb_debug_comm_transport: load THIS library instead of librccl.so.1
+#ifdef NB_TEST_HOOKS
+std::string g_transport_path;                             // nb_debug_comm_transport (test build only): load THIS library instead of librccl.so.1
+#endif
 
 template <typename F> bool sym(void *lib, const char *name, F &fn)
 {
@@ -66,10 +69,13 @@ int load_rccl()
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return NB_OK;
     void *lib = nullptr;
+#ifdef NB_TEST_HOOKS
     if (!g_transport_path.empty()) {
         lib = dlopen(g_transport_path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) return nb_fail(NB_ENODEVICE, "nb_comm: the transport named with nb_debug_comm_transport is not loadable (%s)", dlerror());
-    } else {
+    } else
+#endif
+    {
         // The RCCL that sits on the SAME HIP / HSA runtime as this library: a process can hold two ROCm stacks (PyTorch bundles
         // its own libamdhip64 / libhsa-runtime64 / librccl under torch/lib), and a bare dlopen("librccl.so.1") returns whichever
         // copy was loaded first — if that is the copy of the OTHER stack, its runtime has never seen a device
@@ -229,8 +235,9 @@ void release(nb_comm *c)
         (void)hipSetDevice(mb.dev);
         if (c->failed) {
             // the peers may be waiting inside a collective this process never joined: synchronising the communication
-            // stream or a plain ncclCommDestroy could block for ever — abort the communicator instead
-            if (mb.nccl) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(mb.nccl); else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl); }
+            // stream or a plain ncclCommDestroy could block for ever — abort the communicator instead; a transport without
+            // ncclCommAbort keeps its communicator (a deliberate LEAK, like the communication stream below: nbody.h says so)
+            if (mb.nccl && g_rccl.CommAbort) (void)g_rccl.CommAbort(mb.nccl);
         } else {
             if (mb.comm) (void)hipStreamSynchronize(mb.comm);
             if (mb.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl);
@@ -349,9 +356,11 @@ int run_schedule(nb_comm *c, const std::vector<nb_comm_op> &ops, float dt)
 
 }  // namespace
 
-// Name the library that provides the nccl* entry points (instead of librccl.so.1).  Test hook: tests/loopback_rccl.hip is an
-// in-process transport over device buffers that lets several ranks share ONE device, so the executor above can be run
-// with 2 and 4 members on a one-GPU box.  Must be called before the first nb_comm_* call that loads the transport.
+#ifdef NB_TEST_HOOKS
+// Name the library that provides the nccl* entry points (instead of librccl.so.1).  TEST BUILD ONLY (include/nbody_debug.h):
+// tests/loopback_rccl.hip is an in-process transport over device buffers that lets several ranks share ONE device, so the
+// executor above can be run with 2 and 4 members on a one-GPU box.  Must be called before the first nb_comm_* call that loads
+// the transport.  The product library has no way to load anything but RCCL.
 extern "C" int nb_debug_comm_transport(const char *path)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
@@ -359,6 +368,7 @@ extern "C" int nb_debug_comm_transport(const char *path)
     g_transport_path = path ? path : "";
     return NB_OK;
 }
+#endif
 
 // NB_OK iff the transport can be loaded in this process (and its version); every rank of a one-process-per-GPU job
 // checks this and the ranks AGREE on it before any of them enters the blocking ncclCommInitRank.
@@ -520,7 +530,8 @@ extern "C" int nb_comm_phase_read(nb_comm *c, int handle, double *phase_ms, uint
     return NB_OK;
 }
 
-// Host-only view of the schedule (no GPU, no RCCL): the operations of one step, in issue order.
+#ifdef NB_TEST_HOOKS
+// Host-only view of the schedule (no GPU, no RCCL): the operations of one step, in issue order.  Test build only.
 extern "C" int nb_debug_comm_schedule(int protocol, int handles, uint64_t block_reals, uint64_t full_reals, int ag_pending,
                                       nb_comm_op *ops_out, size_t cap, size_t *count)
 {
@@ -532,3 +543,4 @@ extern "C" int nb_debug_comm_schedule(int protocol, int handles, uint64_t block_
     if (ops_out) memcpy(ops_out, ops.data(), (ops.size() < cap ? ops.size() : cap) * sizeof(nb_comm_op));
     return NB_OK;
 }
+#endif

@@ -43,11 +43,10 @@ template <typename real> struct vec2_of;
 template <> struct vec2_of<float> { typedef float2 type; };
 template <> struct vec2_of<double> { typedef double2 type; };
 
-// Stores of data that ANOTHER workgroup of the same launch will read (the persistent step pipeline, sym_pipeline_f32):
-// WT = write-through (`sc1`): the bytes leave this XCD's L2 for memory at once, so the publisher needs no agent-scope
-// release fence (a buffer_wbl2 per item cost the pipeline 25-65 us of workgroup time: profiles/r04_pipeline_ab_fences.log)
-// — only its own `s_waitcnt vmcnt(0)` before it signals (cdna_hip_programming.md Guideline 16, R1).  WT = false is the plain
-// store of the kernels whose results are consumed after a launch boundary.
+// Slab stores of the symmetric kernels.  WT = write-through (`sc1`): the bytes leave this XCD's L2 for memory at once instead of
+// staying dirty there until the kernel's end flushes them — the partials are read by the NEXT launch only (force_sym_f32 below:
+// -1.8 % step time at N = 25 000, -0.7 % at 65 536, neutral at 262 144, same bits; profiles/r04_write_through_ab.log).
+// WT = false is the plain store.
 template <bool WT>
 __device__ __forceinline__ void store8(float2 *p, float2 v)
 {
@@ -67,17 +66,6 @@ __device__ __forceinline__ void store16(float4 *p, float4 v)
     } else *p = v;
 }
 
-// Loads of positions that ANOTHER workgroup of the same launch may have written (the pipeline's item bodies: the tiles an item
-// reads were advanced by gather pieces running elsewhere): LC = an `sc1` load — it bypasses this CU's vector L1, the only cache
-// that can hold a stale copy (per-XCD L2s are kept coherent by probes; MI355X_MICROARCH.md, inter-workgroup visibility) — in
-// place of an agent-scope acquire fence per item.  The producer side is store8<true> + drain + barrier + atomic, as for the slabs.
-template <bool LC>
-__device__ __forceinline__ float2 load_pos(const float2 *p)
-{
-    if constexpr (LC) return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
-}
-
 // ---------------------------------------------------------------------------
 // kick_drift_one — Simulation::iterate after attract(), Simulation.hpp:129-163, for ONE owned
 // particle whose summed acceleration is `a`: acc <- a; v += a dt; [clamp :133-137];
@@ -89,7 +77,7 @@ enum { INTEG_KICK = 1, INTEG_DRIFT = 2 };
 
 // v, x: the particle's velocity and position, loaded by the caller (sym_gather_block loads them before it sums, so that the
 // two loads are not one more memory latency at the end of a latency-bound kernel); unused unless flags has INTEG_KICK.
-template <typename real, bool STRICT, bool WT = false>
+template <typename real, bool STRICT>
 __device__ __forceinline__
 void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::type v, const typename vec2_of<real>::type x, uint32_t li,
                        typename vec2_of<real>::type *__restrict__ pos_next,
@@ -98,8 +86,7 @@ void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::t
                        uint32_t i_begin, real dt_kick, real dt_drift, int extras, int flags)
 {
     typedef typename vec2_of<real>::type real2;
-    static_assert(!WT || sizeof(real) == 4, "write-through stores: the fp32 pipeline only");
-    if constexpr (WT) store8<true>(&acc[li], a); else acc[li] = a;
+    acc[li] = a;
     if (!(flags & INTEG_KICK)) return;              // acceleration gather only
     if constexpr (STRICT) {
 #pragma clang fp contract(off)
@@ -134,7 +121,7 @@ void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::t
             v.y *= (real)0.9995f;
         }
     }
-    if constexpr (WT) store8<true>(&vel[li], v); else vel[li] = v;
+    vel[li] = v;
     if (flags & INTEG_DRIFT) {
         real2 xn;
         if constexpr (STRICT) {
@@ -145,11 +132,11 @@ void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::t
             xn.x = __builtin_fma(v.x, dt_drift, x.x);
             xn.y = __builtin_fma(v.y, dt_drift, x.y);
         }
-        if constexpr (WT) store8<true>(&pos_next[i_begin + li], xn); else pos_next[i_begin + li] = xn;
+        pos_next[i_begin + li] = xn;
     }
 }
 
-template <typename real, bool STRICT, bool WT = false>
+template <typename real, bool STRICT>
 __device__ __forceinline__
 void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
                     const typename vec2_of<real>::type *__restrict__ pos_cur,
@@ -161,7 +148,7 @@ void kick_drift_one(typename vec2_of<real>::type a, uint32_t li,
     typename vec2_of<real>::type v, x;
     v.x = v.y = x.x = x.y = 0;
     if (flags & INTEG_KICK) { v = vel[li]; x = pos_cur[i_begin + li]; }
-    kick_drift_loaded<real, STRICT, WT>(a, v, x, li, pos_next, vel, acc, i_begin, dt_kick, dt_drift, extras, flags);
+    kick_drift_loaded<real, STRICT>(a, v, x, li, pos_next, vel, acc, i_begin, dt_kick, dt_drift, extras, flags);
 }
 
 // ---------------------------------------------------------------------------
@@ -214,8 +201,6 @@ __device__ __forceinline__ float quake_rsqrt(float number)
 // fast_inv_sqrt on an array: both device forms (scalar as in force_seq_f32, packed as in the tiled / symmetric
 // kernels) — for the bit-exact check against the reference's golden grid (nb_debug_fast_inv_sqrt).
 __device__ __forceinline__ v2f quake_rsqrt2(v2f t);
-__global__ __launch_bounds__(BLOCK)
-void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar, float *__restrict__ y_packed, uint32_t n);
 
 __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
 {
@@ -226,6 +211,7 @@ __device__ __forceinline__ v2f quake_rsqrt2(v2f t)
     return y * (c15 - (t * half * y * y));
 }
 
+#ifdef NB_TEST_HOOKS   // nb_debug_fast_inv_sqrt (include/nbody_debug.h): test build only
 __global__ __launch_bounds__(BLOCK)
 void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar, float *__restrict__ y_packed, uint32_t n)
 {
@@ -235,6 +221,7 @@ void quake_rsqrt_array(const float *__restrict__ x, float *__restrict__ y_scalar
     const v2f p = quake_rsqrt2((v2f){x[i], x[i ^ 1u] });       // the neighbour rides in the other half (n is even or i^1 < n is checked by the host)
     y_packed[i] = p.x;
 }
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -496,7 +483,7 @@ enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
 // WS (wave split, force_sym_f32<..., WS = true>): the 4 waves of the workgroup hold the SAME stationary particles and
 // take the item's chunks in turn (wave w: chunks w, w + 4, ...), so a travelling partial is complete inside ONE wave
 // and is stored straight from the registers: no LDS combine, no barrier per chunk.
-template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false, bool LC = false>
+template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -514,7 +501,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
     auto fetch = [&](uint32_t j, float &x, float &y, float &m, float &e) {
         x = PAD_XY; y = PAD_XY; m = MS ? -1.0f : 0.f; e = eps2;
         if (j < n) {
-            const float2 pj = load_pos<LC>(pos + j);
+            const float2 pj = pos[j];
             if constexpr (MS) { const float sg = sigma[j]; x = pj.x * sg; y = pj.y * sg; m = -sg; e = (sg * sg) * eps2; }
             else { x = pj.x; y = pj.y; if constexpr (!UM) m = mass[j]; }
         }
@@ -624,7 +611,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
 // The stationary accumulators become per-particle pairs {from q0, from q1} (32 registers instead of 16), summed at the
 // end.  An odd chunk count leaves the second half of the last pair empty (PAD particles: half of that pair's work is
 // wasted), so the planner cuts items into even chunk counts for handles that run this kernel (SymTuning::even_chunks).
-template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false, bool LC = false>
+template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
                  float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
@@ -644,11 +631,11 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
         x = (v2f){PAD_XY, PAD_XY}; y = x; m = (v2f){0.f, 0.f};
         if (c < cnt) {
             const uint32_t j = (c0 + c) * SYM_CH + lane;
-            if (j < n) { const float2 pj = load_pos<LC>(pos + j); x.x = pj.x; y.x = pj.y; if constexpr (!UM) m.x = mass[j]; }
+            if (j < n) { const float2 pj = pos[j]; x.x = pj.x; y.x = pj.y; if constexpr (!UM) m.x = mass[j]; }
         }
         if (c + 1 < cnt) {
             const uint32_t j = (c0 + c + 1) * SYM_CH + lane;
-            if (j < n) { const float2 pj = load_pos<LC>(pos + j); x.y = pj.x; y.y = pj.y; if constexpr (!UM) m.y = mass[j]; }
+            if (j < n) { const float2 pj = pos[j]; x.y = pj.x; y.y = pj.y; if constexpr (!UM) m.y = mass[j]; }
         }
     };
     constexpr uint32_t CS = WS ? 8u : 2u;              // WS: wave w sweeps the chunk pairs 2w, 2w + 8, ...
@@ -745,7 +732,7 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
 // cross-wave combine (no barrier inside the sweep), and an item's stationary row is 4 KiB instead of 16.  The four
 // waves' stationary sums are added once, at the end, through LDS in wave order.  Price: four times the travelling
 // partials per pair (one per 512 x 64 instead of 2048 x 64 pairs), which is why large systems keep the classic form.
-template <int RSQ, int MM, bool PAIRS = false, bool WS = false, bool WT = false, bool LC = false>
+template <int RSQ, int MM, bool PAIRS = false, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                         const SymItem it,
@@ -772,18 +759,18 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
         // particles past the end sit at PAD_XY with mass 0: they neither feel nor exert force
         float2 p0 = make_float2(PAD_XY, PAD_XY), p1 = p0;
         float m0 = 0.f, m1 = 0.f;
-        if (g0 < n) { p0 = load_pos<LC>(pos + g0); if constexpr (!UM) m0 = mass[g0]; }
-        if (g1 < n) { p1 = load_pos<LC>(pos + g1); if constexpr (!UM) m1 = mass[g1]; }
+        if (g0 < n) { p0 = pos[g0]; if constexpr (!UM) m0 = mass[g0]; }
+        if (g1 < n) { p1 = pos[g1]; if constexpr (!UM) m1 = mass[g1]; }
         xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; mi[p] = (v2f){m0, m1};
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
     if constexpr (PAIRS) {
-        if (diag) sym_chunks2<RSQ, MM, true, WS, WT, LC>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
-        else      sym_chunks2<RSQ, MM, false, WS, WT, LC>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
+        if (diag) sym_chunks2<RSQ, MM, true, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
+        else      sym_chunks2<RSQ, MM, false, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
     } else {
-        if (diag) sym_chunks<RSQ, MM, true, WS, WT, LC>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
-        else      sym_chunks<RSQ, MM, false, WS, WT, LC>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        if (diag) sym_chunks<RSQ, MM, true, WS, WT>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
+        else      sym_chunks<RSQ, MM, false, WS, WT>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     }
 
     float2 *__restrict__ out = slab_s + (size_t)s_row * SB;
@@ -877,7 +864,7 @@ __device__ __forceinline__ void load_pair(const double2 *__restrict__ p, double2
 // wave-split plans); tile g's stationary rows are
 // [row_lo[g], row_hi[g]), its coverage entries cov[cov_begin[g] .. cov_begin[g + 1]).  Segment bounds are
 // multiples of 64 (or n) and segment offsets even (nb_plan.cpp), so a pair (k, k + 1), k even, is covered together.
-template <typename real, bool FUSE, bool WT = false>
+template <typename real, bool FUSE>
 __device__ __forceinline__
 void sym_gather_block(uint32_t blk,
                 const typename vec2_of<real>::type *__restrict__ slab_s,
@@ -947,7 +934,7 @@ void sym_gather_block(uint32_t blk,
 #pragma unroll
         for (int j = 1; j < GATHER_Q; ++j) { t.x += part[j][f].x; t.y += part[j][f].y; }
         if (base) { const real2 bb = base[lf]; t.x += bb.x; t.y += bb.y; }
-        if constexpr (FUSE) kick_drift_loaded<real, false, WT>(t, vf, xf, lf, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
+        if constexpr (FUSE) kick_drift_loaded<real, false>(t, vf, xf, lf, pos_next, vel, acc, k0, dt_kick, dt_drift, extras, flags);
         else acc_sum[k0 + lf] = t;
     }
 }
@@ -969,343 +956,6 @@ void sym_gather(const typename vec2_of<real>::type *__restrict__ slab_s,
 {
     sym_gather_block<real, FUSE>(blockIdx.x, slab_s, slab_r, row_lo, row_hi, cov_begin, cov, n, k0, kn, acc_sum, base, pos_cur, pos_next, vel, acc,
                                  dt_kick, dt_drift, extras, flags, sb_shift);
-}
-
-// ---------------------------------------------------------------------------
-// sym_step_f32 — ONE launch per step: the force items AND the gather + kick + drift of a whole-system handle (round 4).
-//
-// Grid = n_items force workgroups followed by ceil(n / GATHER_P) gather workgroups.  Workgroups are dispatched in index
-// order, so the gather workgroups take the slots the LAST force items leave free: the launch's drain, where CUs stand
-// partly idle anyway.  A gather workgroup sums 64 particles of ONE tile g (sym_gather_block: the same rows in the same
-// order and association as the sym_gather launch it replaces -> bit-identical trajectories) once every force item that
-// contributes to tile g has finished:
-//   done[g]   arrivals at tile g (monotonic over the handle's life, modulo 2^32): a finished item adds one to its
-//             stationary tile and to every tile its travelling chunks lie in; tile g is complete for the handle's
-//             `epoch`-th fused launch when done[g] == expected[g] * epoch.
-// The item list is tile-major (nb_plan.cpp), so tiles complete in ascending order while the launch runs and only the
-// last few tiles' gathers are left when the last item ends: the step costs ONE launch boundary and no gather launch
-// (two boundaries + 8.6 us of gather at N = 25 000, 13 us at 65 536, 48 us at 262 144).
-// Progress: force workgroups never wait; a gather workgroup waits only for force workgroups, all of which precede it
-// in dispatch order (they run or have finished when it starts — and if a device ever dispatched out of order, a
-// waiting gather workgroup holds one slot, never all of a launch's: the undispatched items start as other slots
-// free).  A wait that does not end within STEP_TIMEOUT sets *err and the workgroup leaves: the host reports NB_EHIP
-// and refuses the handle.
-// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): producer =
-// write-through (sc1) stores of the slab bytes -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 agent-scope
-// atomic add; consumer = relaxed agent-scope poll -> lane 0 agent ACQUIRE fence -> barrier -> plain vector loads.
-// The gather's own outputs (x, v, a) are read by the NEXT launch: plain stores.
-// ---------------------------------------------------------------------------
-constexpr unsigned long long STEP_TIMEOUT_TICKS = 400000000ull;      // 4 s of the 100 MHz real-time counter
-
-struct StepArgs {
-    const float2 *pos_cur;
-    float2 *pos_next;
-    const float *mass, *sigma;
-    const SymItem *items;
-    float2 *slab_s, *slab_r;
-    const uint32_t *row_lo, *row_hi, *cov_begin;
-    const SymCov *cov;
-    const uint32_t *expected;        // items touching each tile
-    uint32_t *done;                  // per-tile arrivals (see above)
-    int *err;                        // page-locked host word: != 0 once a wait has been given up
-    float2 *vel, *acc;
-    uint32_t n, n_items, sb_shift, epoch;
-    float eps2, um_mass, dt;
-    int extras;
-    uint32_t *ticket;                // dynamic work items of the force part (sym_item_index); NULL = item = workgroup index
-    uint32_t first_wave, ticket_base;
-};
-constexpr uint32_t STEP_CTR_STRIDE = 32;     // words between two tiles' counters: one 128-byte line each (arrivals and polls of different tiles do not queue behind each other)
-
-template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
-__global__ __launch_bounds__(BLOCK, (PAIRS ? 3 : 4))
-void sym_step_f32(const StepArgs a)
-{
-    const uint32_t t = threadIdx.x;
-    if (blockIdx.x < a.n_items) {
-        const SymItem it = a.items[sym_item_index(a.ticket, a.first_wave, a.ticket_base)];     // a force workgroup draws its item like any other
-        force_sym_f32_body<RSQ, MM, PAIRS, WS, true>(a.pos_cur, a.mass, a.sigma, it, a.slab_s, a.slab_r, a.n, a.eps2, a.um_mass);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through slab stores have left
-        __syncthreads();                                     // ... every wave's
-        if (t == 0) {
-            __hip_atomic_fetch_add(a.done + (size_t)it.tile * STEP_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!it.diag) {
-                const uint32_t lastp = min((it.c0 + it.cnt) * SYM_CH, a.n) - 1u;
-                for (uint32_t g = (it.c0 * SYM_CH) >> a.sb_shift; g <= lastp >> a.sb_shift; ++g)
-                    __hip_atomic_fetch_add(a.done + (size_t)g * STEP_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-    // ---- gather workgroup: 64 particles of tile g
-    __shared__ uint32_t sh_ok;
-    const uint32_t blk = blockIdx.x - a.n_items;
-    if (t == 0) {
-        const uint32_t g = (blk * (uint32_t)GATHER_P) >> a.sb_shift;
-        const uint32_t want = a.expected[g] * a.epoch;       // modulo 2^32, like the counter
-        uint32_t ok = 1u;
-        const uint32_t *ctr = a.done + (size_t)g * STEP_CTR_STRIDE;
-        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (uint32_t spins = 1;; ++spins) {
-                __builtin_amdgcn_s_sleep(16);                // ~0.5 us between polls (polling cost, MI355X_MICROARCH.md)
-                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) break;
-                if ((spins & 63u) != 0u) continue;           // the give-up word and the clock: every 64th poll
-                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { ok = 0u; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > STEP_TIMEOUT_TICKS) {
-                    __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ok = 0u;
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the slabs were in memory before the counter said so
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sh_ok = ok;
-    }
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((int)sh_ok) == 0) return;
-    sym_gather_block<float, true, false>(blk, a.slab_s, a.slab_r, a.row_lo, a.row_hi, a.cov_begin, a.cov, a.n, 0u, a.n, nullptr, nullptr,
-                                         a.pos_cur, a.pos_next, a.vel, a.acc, a.dt, a.dt, a.extras, INTEG_KICK | INTEG_DRIFT, a.sb_shift);
-}
-
-// ---------------------------------------------------------------------------
-// sym_pipeline_f32 — the whole step LOOP of a single handle as ONE persistent launch.
-//
-// What it replaces: per step, force_sym_f32 (one workgroup per item) + sym_gather (sum of the slabs, kick, drift) — two
-// dependent launches whose boundaries, fill and drain cost a short step a quarter of its time (N = 25 000: 74 us of VALU
-// work at the clock the part holds, 100 us per step; tools/sym_timeline.hip, profiles/r04_sym_timeline.log).  Here
-// `grid` resident workgroups draw (step, item) tickets from ONE in-order queue and run the SAME item body; what a
-// launch boundary used to order is ordered by two per-TILE counters (monotonic over the handle's life, each on a
-// 128-byte line of its own — with all tiles' counters packed into a few lines every arrival and poll of the chip stood
-// in the same queue and the pipeline was 2-3 x slower than this):
-//   done[g]      arrivals at tile g: every finished item adds one to each tile it touched (its stationary tile and the
-//                tiles its travelling chunks lie in).  The add that completes expected[g] x (step + 1) makes its
-//                workgroup the LAST ARRIVER of tile g for that step: it gathers the tile at once — pipe_gather_tile: the
-//                sums of sym_gather in its order and association, then kick and drift, the WHOLE tile by this one
-//                workgroup with eight rows per thread in flight (60-150 us for 2048 particles; cut into 64-particle
-//                pieces claimed by helpers, the first version, a tile took one workgroup 0.5-1.5 ms and the next step's
-//                items queued up behind it) — and publishes
-//   ready[g]     = number of steps tile g's positions have been advanced.  An item of step k starts once ready[] >= k
-//                for the tiles it touches.
-// Why that is enough, with the slabs and position replicas SINGLE / DOUBLE buffered as before: an item's outputs (its
-// stationary row, its travelling partials) are read only by the gathers of the tiles it touches — exactly the gathers
-// it waits for; the replica a gather of step k writes was last read by step k - 1's items touching that tile, all of
-// which arrived before the step k - 1 gather that this step's items waited for.
-// Progress: tickets are drawn in order; an item waits only for gathers of EARLIER tickets' steps; a gather is done by
-// the last of those items to arrive, which waits for nothing — no cycle, whatever the placement; every workgroup
-// leaves when the queue is empty.  A wait that does not end within PIPE_TIMEOUT (a bug, never a legal state) sets *err
-// and every workgroup drains: the host reports NB_EHIP and refuses the handle, the GPU is never left spinning.
-// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): every handed-off
-// byte is stored WRITE-THROUGH (sc1: store8 / store16 <WT>) -> every wave s_waitcnt vmcnt(0) -> barrier -> agent-scope
-// atomic (no release fence: a buffer_wbl2 per item cost 25-65 us of workgroup time).  Consumers: an item reads only
-// POSITIONS out of what the launch has written, with sc1 loads (load_pos<true>: they bypass the CU's vector L1, the only
-// cache that can be stale) behind poll + barrier, no fence; a gather reads slabs, velocities and positions with plain
-// loads behind ONE agent-scope acquire fence per tile.
-// The sums keep sym_gather's association, so the trajectory is BIT-IDENTICAL to the two-launch path
-// (tests/test_pipeline_gpu.py) — which is also how a stale read would show.
-// ---------------------------------------------------------------------------
-typedef unsigned long long u64_t;
-constexpr u64_t PIPE_TIMEOUT_TICKS = 400000000ull;       // 4 s of the 100 MHz real-time counter
-
-constexpr uint32_t PIPE_CTR_STRIDE = 16;     // u64 words between two counters: every counter of every tile on a 128-byte line of its own
-#define PIPE_AT(base, g) ((base) + (size_t)(g) * PIPE_CTR_STRIDE)
-
-struct PipeArgs {
-    const float2 *pos[2];            // replica read by even / odd local steps is pos[(cur0 + step) & 1]
-    float2 *pos_w[2];                // the same two buffers, writable
-    const float *mass, *sigma;
-    const SymItem *items;
-    const uint32_t *order;           // ticket i of a step runs item order[i] (see PIPE ORDER in nb_capi.hip)
-    float2 *slab_s, *slab_r;
-    const uint32_t *row_lo, *row_hi, *cov_begin;
-    const SymCov *cov;
-    const uint32_t *expected;        // items touching each tile
-    float2 *vel, *acc;
-    u64_t *head, *done, *ready;      // ticket counter; per-tile counters (see above)
-    int *err;
-    u64_t *dbg;                      // optional (nb_debug_pipeline_watch): page-locked host words, one per workgroup: what it is doing now
-    uint32_t n, n_items, tiles, sb_shift, steps, cur0;
-    u64_t epoch0, ticket0;           // steps / tickets this handle's pipeline had completed before the launch
-    float eps2, um_mass, dt;
-    int extras;
-};
-
-__device__ __forceinline__ u64_t pipe_load(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// what this workgroup is doing, for a host that watches a launch (debugging aid; a.dbg is NULL otherwise): code << 56 | tile << 32 | low word
-enum { PIPE_DBG_TICKET = 1, PIPE_DBG_WAIT = 2, PIPE_DBG_BODY = 4, PIPE_DBG_ARRIVED = 5, PIPE_DBG_EXIT = 6, PIPE_DBG_GATHER = 7 };
-__device__ __forceinline__ void pipe_dbg(const PipeArgs &a, uint32_t code, uint32_t g, uint32_t low)
-{
-    if (a.dbg && threadIdx.x == 0)
-        __hip_atomic_store(a.dbg + blockIdx.x, ((u64_t)code << 56) | ((u64_t)(g & 0xffffffu) << 32) | low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// All threads of the last arriver: the gather of tile g for absolute step j, the whole tile by this workgroup.  Thread t takes the
-// particle pair (2 t, 2 t + 1) of each 512-particle pass and keeps sym_gather_block's EIGHT partial sums of it in registers — partial q
-// = the rows r0 + q, r0 + q + 8, ... then the coverage entries c0 + q, c0 + q + 8, ..., in that order — so that eight rows (and
-// then eight coverage entries) are in flight per thread at once; the partials are added in q order, then kick and drift: the same
-// operations in the same order as the gather launch, bit for bit.  Ends with ready[g] = j + 1.
-__device__ __forceinline__ void pipe_gather_tile(const PipeArgs &a, uint32_t g, u64_t j)
-{
-    const uint32_t t = threadIdx.x;
-    pipe_dbg(a, PIPE_DBG_GATHER, g, (uint32_t)j);
-    if (t == 0) {                                            // the slabs, velocities and positions of this tile were written elsewhere
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const bool odd = ((a.cur0 + (uint32_t)(j - a.epoch0)) & 1u) != 0;
-    const float2 *__restrict__ pos_cur = odd ? a.pos[1] : a.pos[0];
-    float2 *__restrict__ pos_next = odd ? a.pos_w[0] : a.pos_w[1];
-    const float2 *__restrict__ slab_s = a.slab_s;
-    const float2 *__restrict__ slab_r = a.slab_r;
-    const uint32_t r0 = a.row_lo[g], r1 = a.row_hi[g], c0 = a.cov_begin[g], c1 = a.cov_begin[g + 1];
-    const uint32_t sb = 1u << a.sb_shift;
-    for (uint32_t pass = 0; pass < sb; pass += 2u * BLOCK) {
-        const uint32_t loc = pass + 2u * t, k = (g << a.sb_shift) + loc;       // this thread's pair: particles k, k + 1 (k even)
-        const bool live = k < a.n;
-        float2 v0 = make_float2(0.f, 0.f), v1 = v0, x0 = v0, x1 = v0;
-        if (live) { v0 = a.vel[k]; x0 = pos_cur[k]; if (k + 1 < a.n) { v1 = a.vel[k + 1]; x1 = pos_cur[k + 1]; } }
-        float2 p0[GATHER_Q], p1[GATHER_Q];
-#pragma unroll
-        for (int q = 0; q < GATHER_Q; ++q) { p0[q] = make_float2(0.f, 0.f); p1[q] = p0[q]; }
-        if (live) {
-            for (uint32_t r = r0; r < r1; r += (uint32_t)GATHER_Q) {
-                float2 b0[GATHER_Q], b1[GATHER_Q];
-#pragma unroll
-                for (int q = 0; q < GATHER_Q; ++q) {         // a row past the end re-reads the last one and is dropped below
-                    const uint32_t rr = r + (uint32_t)q < r1 ? r + (uint32_t)q : r1 - 1u;
-                    load_pair(slab_s + ((size_t)rr << a.sb_shift) + loc, b0[q], b1[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < GATHER_Q; ++q)
-                    if (r + (uint32_t)q < r1) { p0[q].x += b0[q].x; p0[q].y += b0[q].y; p1[q].x += b1[q].x; p1[q].y += b1[q].y; }
-            }
-            for (uint32_t i = c0; i < c1; i += (uint32_t)GATHER_Q) {
-                SymCov cv[GATHER_Q];
-                bool in[GATHER_Q];
-#pragma unroll
-                for (int q = 0; q < GATHER_Q; ++q) {
-                    in[q] = i + (uint32_t)q < c1;
-                    cv[q] = a.cov[in[q] ? i + (uint32_t)q : c1 - 1u];
-                }
-                float2 b0[GATHER_Q], b1[GATHER_Q];
-#pragma unroll
-                for (int q = 0; q < GATHER_Q; ++q) {
-                    in[q] = in[q] && k >= cv[q].lo && k < cv[q].hi;
-                    load_pair(slab_r + (in[q] ? cv[q].base + (int64_t)k : (int64_t)0), b0[q], b1[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < GATHER_Q; ++q) {
-                    if (!in[q]) continue;
-                    p0[q].x += b0[q].x; p0[q].y += b0[q].y;
-                    if (k + 1 < cv[q].hi) { p1[q].x += b1[q].x; p1[q].y += b1[q].y; }
-                }
-            }
-            float2 s0 = p0[0], s1 = p1[0];
-#pragma unroll
-            for (int q = 1; q < GATHER_Q; ++q) { s0.x += p0[q].x; s0.y += p0[q].y; s1.x += p1[q].x; s1.y += p1[q].y; }
-            kick_drift_loaded<float, false, true>(s0, v0, x0, k, pos_next, a.vel, a.acc, 0u, a.dt, a.dt, a.extras, INTEG_KICK | INTEG_DRIFT);
-            if (k + 1 < a.n)
-                kick_drift_loaded<float, false, true>(s1, v1, x1, k + 1, pos_next, a.vel, a.acc, 0u, a.dt, a.dt, a.extras, INTEG_KICK | INTEG_DRIFT);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores of x, v, a have left
-    __syncthreads();                                        // ... every wave's
-    if (t == 0) __hip_atomic_store(PIPE_AT(a.ready, g), j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Lane 0 of the workgroup: until tile g has been advanced to step k.  False if the launch has been given up.
-__device__ __forceinline__ bool pipe_spin_tile(const PipeArgs &a, uint32_t g, u64_t k)
-{
-    if (pipe_load(PIPE_AT(a.ready, g)) >= k) return true;
-    const u64_t t0 = __builtin_amdgcn_s_memrealtime();
-    for (uint32_t spins = 1;; ++spins) {
-        __builtin_amdgcn_s_sleep(32);                       // ~1 us between polls: hundreds of workgroups may be waiting (polling-cost, MI355X_MICROARCH.md)
-        if (pipe_load(PIPE_AT(a.ready, g)) >= k) return true;
-        if ((spins & 63u) != 0u) continue;                  // the give-up word and the clock: every 64th poll
-        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > PIPE_TIMEOUT_TICKS) {
-            __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
-        }
-    }
-}
-
-// Occupancy is pinned to what the item body gets as a kernel of its own (4 waves per SIMD, 3 with chunk pairs): without
-// the bound the allocator lets the general-mass pair variants grow to 248 VGPRs (2 waves per SIMD).
-template <int RSQ, int MM, bool PAIRS = false, bool WS = false>
-__global__ __launch_bounds__(BLOCK, (PAIRS ? 3 : 4))
-void sym_pipeline_f32(const PipeArgs a)
-{
-    __shared__ u64_t sh_ticket;
-    __shared__ uint32_t sh_word, sh_mask;
-    const uint32_t t = threadIdx.x;
-    const u64_t total = (u64_t)a.steps * a.n_items;
-    for (;;) {
-        if (t == 0) sh_ticket = __hip_atomic_fetch_add(a.head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket0;
-        __syncthreads();
-        // every loop-control value of this kernel is made PROVABLY wave-uniform (readfirstlane): the branches are scalar
-        const u64_t q = ((u64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sh_ticket >> 32)) << 32) |
-                        (u64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sh_ticket);
-        pipe_dbg(a, PIPE_DBG_TICKET, 0u, (uint32_t)q);
-        if (q >= total) break;                              // the queue is empty: every workgroup gets here
-        const uint32_t step = (uint32_t)(q / a.n_items), i = (uint32_t)(q % a.n_items);
-        const u64_t k = a.epoch0 + step;                    // absolute step of this handle's pipeline
-        const SymItem it = a.items[a.order[i]];
-        const uint32_t lastp = min((it.c0 + it.cnt) * SYM_CH, a.n) - 1u;
-        const uint32_t t_lo = it.diag ? it.tile : (it.c0 * SYM_CH) >> a.sb_shift, t_hi = it.diag ? it.tile : lastp >> a.sb_shift;
-        // ---- wait until the tiles this item reads have been advanced to step k.  ONE look at all of them — lane l of wave 0 reads
-        // the counter of tile l of the item (0: its stationary tile; 1 + j: tile t_lo + j of its chunks; at most 32, see the host's
-        // span check) — and one barrier; only if some tile is behind, lane 0 waits for them one by one.
-        const uint32_t ntiles = it.diag ? 1u : 2u + (t_hi - t_lo);
-        if (t < 64u) {
-            bool behind = false;
-            if (t < ntiles) behind = pipe_load(PIPE_AT(a.ready, t == 0u ? it.tile : t_lo + t - 1u)) < k;
-            const unsigned long long any = __builtin_amdgcn_ballot_w64(behind);
-            if (t == 0) {
-                uint32_t okw = 1u;
-                if (any != 0ull) {
-                    pipe_dbg(a, PIPE_DBG_WAIT, it.tile, (uint32_t)k);
-                    okw = pipe_spin_tile(a, it.tile, k) ? 1u : 0u;
-                    if (!it.diag) for (uint32_t g = t_lo; okw && g <= t_hi; ++g) okw = pipe_spin_tile(a, g, k) ? 1u : 0u;
-                }
-                sh_word = okw;
-            }
-        }
-        __syncthreads();
-        const bool ok = __builtin_amdgcn_readfirstlane((int)sh_word) != 0;
-        if (!ok) break;                                     // the launch has been given up (time-out somewhere): drain
-        // no acquire fence: the only bytes an item reads that this launch has written are positions, and every load of them is an
-        // `sc1` load (load_pos<true>), behind the barrier above
-        const bool odd = ((a.cur0 + step) & 1u) != 0;
-        const float2 *__restrict__ pos_cur = odd ? a.pos[1] : a.pos[0];
-        pipe_dbg(a, PIPE_DBG_BODY, it.tile, (uint32_t)q);
-        force_sym_f32_body<RSQ, MM, PAIRS, WS, true, true>(pos_cur, a.mass, a.sigma, it, a.slab_s, a.slab_r, a.n, a.eps2, a.um_mass);
-        // ---- publish: the slab stores are write-through; every wave drains its own, then lane l of wave 0 adds the arrival at tile l
-        // of the item (the adds are in flight together); a lane whose add completed its tile sets its bit
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t < 64u) {
-            bool last = false;
-            if (t < ntiles) {
-                const uint32_t g = t == 0u ? it.tile : t_lo + t - 1u;
-                const u64_t old = __hip_atomic_fetch_add(PIPE_AT(a.done, g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = old + 1 == (u64_t)a.expected[g] * (k + 1);
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(last);
-            if (t == 0) sh_mask = (uint32_t)m;              // bit l: this workgroup is the last arriver of the item's tile l
-        }
-        pipe_dbg(a, PIPE_DBG_ARRIVED, it.tile, (uint32_t)q);
-        __syncthreads();
-        for (uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_mask); mask; mask &= mask - 1u) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(mask);
-            pipe_gather_tile(a, bit == 0u ? it.tile : t_lo + bit - 1u, k);
-        }
-        __syncthreads();                                    // sh_ticket / sh_word / sh_mask are rewritten by the next turn
-    }
-    pipe_dbg(a, PIPE_DBG_EXIT, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------

@@ -12,7 +12,7 @@
 
 #include <vector>
 
-#include "nbody.h"
+#include "nbody_debug.h"   /* nb_comm_op, NB_OP_*, NB_EV_*: the schedule is data (the types live beside the hook that exposes it) */
 
 namespace nbk {
 

@@ -71,12 +71,18 @@ class Watchdog:
     culprit instead of a silent hang.  The blocked calls (torch.distributed, HIP synchronisation, ctypes) all release the
     GIL, so the timer thread runs.  ``seconds`` <= 0 disables it."""
 
+    #: last resort of the PROCESS, set by a host that already holds a valid result when it starts something optional
+    #: (bench.py: the line of the plain all-gather configuration, measured before any faster candidate is tried):
+    #: called on expiry with the message, after it went to stderr; an int it returns replaces EXIT_DEADLINE as the status.
+    last_resort: Optional[Callable[[str], Optional[int]]] = None
+
     def __init__(self, seconds: float, what: str, report: Optional[Callable[[], object]] = None, rank: Optional[int] = None,
                  exit_fn: Callable[[int], None] = os._exit):
         self.seconds, self.what, self.report, self.rank, self.exit_fn = float(seconds), what, report, rank, exit_fn
         self._timer: Optional[threading.Timer] = None
 
     def _expire(self) -> None:
+        code = EXIT_DEADLINE
         try:
             who = f"rank {self.rank}: " if self.rank is not None else ""
             msg = f"[nbodysim_amd watchdog] {who}deadline of {self.seconds:.0f} s expired while {self.what}"
@@ -87,8 +93,16 @@ class Watchdog:
                     msg += f" | (report failed: {e})"
             sys.stderr.write(msg + "\n")
             sys.stderr.flush()
+            hook = Watchdog.last_resort
+            if hook is not None:
+                try:
+                    alt = hook(msg)
+                    if isinstance(alt, int):
+                        code = alt
+                except Exception as e:      # nor may the last resort
+                    sys.stderr.write(f"[nbodysim_amd watchdog] last resort failed: {e}\n")
         finally:
-            self.exit_fn(EXIT_DEADLINE)
+            self.exit_fn(code)
 
     def __enter__(self):
         if self.seconds > 0:
@@ -221,21 +235,133 @@ def agree_on_fastest(local_seconds: Dict[str, float], group=None,
 
 
 def time_candidates(names: Sequence[str], run_one: Callable[[str, Dict[str, float]], float], group=None, deadline_s: float = 120.0,
-                    rank: int = 0, prefer: Sequence[str] = (), log: Optional[Callable[[str], None]] = None):
+                    rank: int = 0, prefer: Sequence[str] = (), log: Optional[Callable[[str], None]] = None,
+                    cleanup: Optional[Callable[[str], None]] = None, failed: Optional[Dict[str, str]] = None):
     """The start-up timing as a pure driver (testable over gloo on the CPU): ``run_one(name, local_so_far)`` runs one
     candidate on this rank and returns its seconds per step (``inf`` = unavailable); candidates run in the order given —
     simplest first, so that the plainest protocol has a number before anything exotic is tried — each under its own
     ``Watchdog``: a rank stuck inside a candidate ends the job with a non-zero exit that NAMES the candidate and lists the
-    timings gathered so far, on every rank that waits for it.  Returns (winner, {name: job seconds}) from
-    ``agree_on_fastest``."""
+    timings gathered so far, on every rank that waits for it.
+    A candidate that RAISES on any rank (and leaves its peers able to go on: see ``DistributedSimulation.step``, which keeps
+    issuing a failed rank's collectives) is not the end of the run: after every candidate the ranks agree on whether it
+    completed everywhere (one all-reduce); if not it counts as unavailable on ALL of them, ``cleanup(name)`` runs (errors
+    ignored), ``failed[name]`` says why, and the next candidate is tried.  Returns (winner, {name: job seconds}) from
+    ``agree_on_fastest`` — which raises only if nothing at all survived."""
     local: Dict[str, float] = {}
+    failed = {} if failed is None else failed
     for name in names:
         with Watchdog(deadline_s, f"timing the start-up candidate '{name}'", report=lambda: dict(local), rank=rank):
-            local[name] = float(run_one(name, local))
+            err: Optional[BaseException] = None
+            try:
+                value = float(run_one(name, local))
+            except Exception as e:       # noqa: BLE001 - whatever it was, the other candidates still deserve their turn
+                err, value = e, float("inf")
+            _, lo, _ = ranks_agree([0 if err is not None else 1], group)
+            if lo[0] == 0:
+                value = float("inf")
+                failed[name] = f"{type(err).__name__}: {err}" if err is not None else "failed on another rank"
+                if cleanup is not None:
+                    try:
+                        cleanup(name)
+                    except Exception:    # noqa: BLE001 - a half-built candidate may not close cleanly
+                        pass
+            local[name] = value
         if log is not None:
             v = local[name]
-            log(f"[tune] rank {rank}: {name}: " + (f"{v * 1e3:.3f} ms/step" if np.isfinite(v) else "unavailable"))
+            log(f"[tune] rank {rank}: {name}: " + (f"{v * 1e3:.3f} ms/step" if np.isfinite(v) else f"unavailable{' (' + failed[name] + ')' if name in failed else ''}"))
     return agree_on_fastest(local, group, prefer=tuple(prefer) if prefer else tuple(names))
+
+
+# ---------------------------------------------------------------------------
+# the sharded trajectory against the unsharded one (north_star: within 1e-5 relative)
+# ---------------------------------------------------------------------------
+PARITY_TOL = 1e-5      # north_star / BASELINE.json: positions and velocities within 1e-5 relative
+
+
+class ParityError(RuntimeError):
+    """The sharded state is further than the tolerance from the unsharded one (``.result`` = the comparison)."""
+
+    def __init__(self, what: str, result: dict):
+        super().__init__(f"parity_check failed ({what}): max rel pos {result.get('max_rel_pos'):.3g}, vel {result.get('max_rel_vel'):.3g} "
+                         f"after {result.get('steps')} steps (tolerance {result.get('tolerance'):g}); worst particle {result.get('worst_particle')} "
+                         f"(block of rank {result.get('worst_rank')}){': ' + result['error'] if result.get('error') else ''}")
+        self.result = result
+
+
+def max_rel(a, b) -> Tuple[float, int]:
+    """(max over particles of |a_i - b_i| / |b_i|, its index): the relative measure of SURVEY §8c (vector norms per
+    particle; a particle at rest at the origin is measured absolutely)."""
+    a = np.asarray(a, np.float64).reshape(len(a), -1)
+    b = np.asarray(b, np.float64).reshape(len(b), -1)
+    den = np.linalg.norm(b, axis=1)
+    r = np.linalg.norm(a - b, axis=1) / np.where(den > 0, den, 1.0)
+    r = np.where(np.isfinite(r), r, np.inf)                 # a NaN anywhere is a failure, not a pass
+    k = int(np.argmax(r)) if len(r) else 0
+    return (float(r[k]) if len(r) else 0.0), k
+
+
+def state_rows(bodies: np.ndarray) -> np.ndarray:
+    """Body records -> float64 rows [pos | vel] (4 columns, 6 for dims = 3): what the parity check compares."""
+    return np.concatenate([np.asarray(bodies["pos"], np.float64), np.asarray(bodies["vel"], np.float64)], axis=1)
+
+
+def gather_rows(owned: np.ndarray, plan: ShardPlan, group=None) -> np.ndarray:
+    """The ranks' owned rows ((i_count, k) float64 each) as one (n, k) array on EVERY rank: one all-gather of equal
+    (stride-row) counts, like the position exchange.  Works over RCCL (device tensors) and gloo (host tensors)."""
+    import torch
+    import torch.distributed as dist
+
+    owned = np.ascontiguousarray(owned, dtype=np.float64)
+    if owned.ndim != 2 or owned.shape[0] != plan.i_count:
+        raise ValueError(f"rank {plan.rank} owns {plan.i_count} rows, got an array of shape {owned.shape}")
+    if plan.world == 1:
+        return owned.copy()
+    dev = _comm_device(group)
+    mine = torch.zeros((plan.stride, owned.shape[1]), dtype=torch.float64)
+    mine[: plan.i_count] = torch.from_numpy(owned)
+    mine = mine.to(dev)
+    full = torch.empty((plan.padded_n, owned.shape[1]), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(full, mine, group=group)
+    return full.cpu().numpy()[: plan.n].copy()
+
+
+def compare_with_unsharded(owned: np.ndarray, plan: ShardPlan, reference: Optional[Callable[[], np.ndarray]], steps: int,
+                           tol: float = PARITY_TOL, group=None, full_out: Optional[list] = None) -> dict:
+    """The self-check of a sharded run: gather every rank's [pos | vel] rows, and on rank 0 compare them with
+    ``reference()`` — the rows of the SAME system advanced the same ``steps`` by ONE unsharded handle (only rank 0 calls
+    it).  The verdict is broadcast, so the dictionary is identical on every rank and all of them take the same branch:
+    {"max_rel_pos", "max_rel_vel", "steps", "tolerance", "ok", "worst_particle", "worst_rank", "error"}.
+    ``full_out``, if a list, receives the gathered (n, k) array (identical on every rank)."""
+    import torch
+    import torch.distributed as dist
+
+    full = gather_rows(owned, plan, group)
+    if full_out is not None:
+        full_out.append(full)
+    res = np.array([np.inf, np.inf, -1.0, 0.0, 0.0])        # pos, vel, worst particle, ok, reference failed
+    err = ""
+    if plan.rank == 0:
+        try:
+            ref = np.asarray(reference(), np.float64)
+            if ref.shape != full.shape:
+                raise ValueError(f"the unsharded reference has shape {ref.shape}, the gathered state {full.shape}")
+            half = full.shape[1] // 2
+            rp, kp = max_rel(full[:, :half], ref[:, :half])
+            rv, kv = max_rel(full[:, half:], ref[:, half:])
+            res[:] = [rp, rv, float(kp if rp >= rv else kv), 1.0 if (rp <= tol and rv <= tol) else 0.0, 0.0]
+        except Exception as e:          # noqa: BLE001 - the other ranks wait in the broadcast below: always get there
+            err = f"the unsharded reference failed on rank 0: {type(e).__name__}: {e}"
+            res[4] = 1.0
+    if plan.world > 1:
+        t = torch.from_numpy(res).to(_comm_device(group))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        res = t.cpu().numpy()
+    worst = int(res[2])
+    if res[4] and not err:
+        err = "the unsharded reference failed on rank 0 (see its stderr)"
+    return {"max_rel_pos": float(res[0]), "max_rel_vel": float(res[1]), "steps": int(steps), "tolerance": float(tol),
+            "ok": bool(res[3] == 1.0), "worst_particle": worst if worst >= 0 else None,
+            "worst_rank": (worst // plan.stride) if worst >= 0 else None, "error": err or None}
 
 
 _AGREE_FIELDS = ("created", "protocol", "chunks_per_item", "cross_units_total", "local_units", "tiles", "cus", "late")
@@ -259,7 +385,14 @@ class DistributedSimulation:
                "c"          the library's own loop (``nb_comm_step``, nbodysim_amd/csrc/nb_comm.cpp): RCCL collectives on
                             a communication stream, event-ordered, ONE foreign call for any number of steps; the RCCL
                             id is created by rank 0 and broadcast through the torch process group.  RCCL only.
-               "tune"       (with protocol="tune") both drivers are candidates of the start-up timing
+               "tune"       both drivers are candidates of the start-up timing (of every protocol of protocol="tune", or
+                            of the one protocol named).  A C-loop candidate may only win if its trial ended in the SAME
+                            BITS as the torch-driven trial of the same protocol (all-gather protocol: required; the
+                            reducing protocols: bit-identical or within 1e-6, RCCL being free to order a sum differently
+                            in another communicator) — ``tuning["validation"]`` says which.
+    verify     (start-up timing only) every candidate's trial state is gathered and compared on rank 0 with ONE unsharded
+               handle advanced the same steps; a candidate further than 1e-5 (north_star's tolerance) from it is
+               disqualified like an unavailable one — a protocol that mis-orders an exchange on this node cannot win.
     Extra keyword arguments go to ``Simulation`` (``sym_late_us``, ``sym_chunks_per_item`` ... the tuning fields of
     ``nb_params``; they must be the same on every rank and are verified to be).
     """
@@ -267,7 +400,7 @@ class DistributedSimulation:
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
                  order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
                  protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, driver: str = "torch",
-                 deadline_s: float = 120.0, **sim_kwargs):
+                 deadline_s: float = 120.0, verify: bool = True, **sim_kwargs):
         import torch
         import torch.distributed as dist
 
@@ -302,10 +435,12 @@ class DistributedSimulation:
         self.comm = None
         self.driver = "torch"
         self.deadline_s = float(deadline_s)     # per start-up candidate and for forming the C-level communicator; <= 0: none
+        self.verify = bool(verify)
+        self._broken: Optional[BaseException] = None   # first failure of a compute call of the torch-driven loop (see step())
 
         extra: dict = {}
-        if protocol == "tune" and world > 1:
-            protocol, extra, driver = self._tune(bodies, tune_steps, tune_dt, driver)
+        if world > 1 and (protocol == "tune" or driver == "tune"):
+            protocol, extra, driver = self._tune(bodies, tune_steps, tune_dt, driver, None if protocol == "tune" else protocol)
         elif protocol == "tune":
             protocol = "auto"
         if driver == "tune":
@@ -321,6 +456,7 @@ class DistributedSimulation:
         torch, world, rank = self.torch, self.plan.world, self.plan.rank
         err: Optional[BaseException] = None
         self.sim = None
+        self._broken = None
         try:
             # full-n position replicas owned by torch so the collective can write them
             self.pos = [torch.zeros((self.plan.padded_n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
@@ -430,12 +566,32 @@ class DistributedSimulation:
             raise RuntimeError(f"rank {rank}: the C-level RCCL communicator could not be formed on every rank"
                                + (f"; this rank: {err}" if err is not None else "")) from err
 
-    def _tune(self, bodies: np.ndarray, steps: int, dt: float, driver: str = "torch"):
+    #: arguments of ``Simulation`` that change the PHYSICS (everything else only shapes launches): what the unsharded
+    #: reference handle of the self-check is created with
+    _PHYSICS_ARGS = ("eps", "precision", "rsqrt", "order", "integrator", "extras", "dims", "uniform_mass", "mass_scaling")
+
+    def reference_rows(self, bodies: np.ndarray, steps: int, dt: float) -> np.ndarray:
+        """[pos | vel] rows of the SAME system advanced ``steps`` steps by ONE unsharded handle on this rank's device —
+        what a sharded trajectory is checked against (``compare_with_unsharded``; rank 0 calls this)."""
+        from .simulation import Simulation
+
+        kw = {k: v for k, v in self._args.items() if k in self._PHYSICS_ARGS}
+        with Simulation(bodies, device=self._device_index, **kw) as ref:
+            ref.advance(steps, dt)
+            return state_rows(ref.sync())
+
+    def owned_rows(self) -> np.ndarray:
+        """[pos | vel] rows of the owned block (float64), after waiting for the enqueued steps."""
+        return state_rows(self.sync())
+
+    def _tune(self, bodies: np.ndarray, steps: int, dt: float, driver: str = "torch", only: Optional[str] = None):
         """Time `steps` steps of each candidate on a scratch copy of the system (2 untimed steps first), wall clock
         between barriers, MAX over ranks; the handles are destroyed again, so the simulation proper starts from
         the caller's bodies at frame 0.  Returns (protocol, extra Simulation keyword arguments, driver).
-        A replicated (all-reduce) candidate must also pass the divergence check on this transport — every rank ends
-        the trial with bit-identical positions — or it is disqualified."""
+        Every candidate must ALSO be right before it may be fast (``verify``): its trial state is compared with one
+        unsharded handle's on rank 0 (1e-5), a replicated (all-reduce) candidate must end with bit-identical replicas on
+        every rank, and a C-loop candidate must reproduce the torch-driven trial of its protocol (see ``driver``).  A
+        candidate that raises on some rank is skipped by agreement (``time_candidates``), not fatal."""
         late_default_on = self.plan.world >= 8 and float(self._args.get("sym_late_us", 0.0)) == 0.0
         flipped = ("symmetric-late", {"sym_late_us": -1.0}) if late_default_on else ("symmetric+late", {"sym_late_us": 40.0})
         # simplest first: north_star's plain all-gather, then one collective per step (all-reduce), then the symmetric
@@ -444,12 +600,23 @@ class DistributedSimulation:
                 flipped[0]: ("symmetric", flipped[1])}
         if float(self._args.get("sym_late_us", 0.0)) != 0.0:      # the caller fixed the late share: nothing to flip
             del base[flipped[0]]
+        if only is not None:                                      # one protocol named: only the drivers compete
+            base = {"auto": (only, {})} if only == "auto" else {k: v for k, v in base.items() if v[0] == only}
         nccl = self.dist.get_backend(self.group) == "nccl"
         drivers = [d for d in (("torch", "c") if driver == "tune" else (driver,)) if d == "torch" or nccl]
         cands = {}
         for d in drivers:                                         # every torch-driven candidate before any C-loop one
             for name, (cand, extra) in base.items():
                 cands[name if d == "torch" else "c:" + name] = (cand, extra, d)
+        trial_steps = 2 + steps
+        reference: Dict[str, np.ndarray] = {}                     # rank 0: the unsharded trial state, computed once
+        states: Dict[str, np.ndarray] = {}                        # gathered trial state of every validated candidate
+        validation: Dict[str, dict] = {}
+
+        def unsharded() -> np.ndarray:
+            if "rows" not in reference:
+                reference["rows"] = self.reference_rows(bodies, trial_steps, dt)
+            return reference["rows"]
 
         def run_one(name: str, local: Dict[str, float]) -> float:
             cand, extra, d = cands[name]
@@ -458,7 +625,7 @@ class DistributedSimulation:
                 return float("inf")                               # not eligible once, not eligible with the late items flipped
             try:
                 self._create(bodies, cand, extra, d)
-            except RuntimeError as e:
+            except RuntimeError as e:                             # raised on EVERY rank (agreed inside _create)
                 if "not eligible" not in str(e) and "communicator could not be formed" not in str(e):
                     raise
                 return float("inf")
@@ -470,17 +637,47 @@ class DistributedSimulation:
             self.wait()
             self.dist.barrier(group=self.group)
             per_step = (time.perf_counter() - t0) / steps
+            v: dict = {}
             if self.replicated and not self.replicas_identical():
-                per_step = float("inf")
+                per_step, v["replicas"] = float("inf"), "diverged: this transport does not hand every rank the same sum"
+            if self.verify:
+                got: list = []
+                v.update(compare_with_unsharded(self.owned_rows(), self.plan, unsharded, trial_steps, group=self.group, full_out=got))
+                if not v["ok"]:
+                    per_step = float("inf")
+                elif d == "c" and name[2:] in states:             # the library's loop against the torch-driven loop, same protocol
+                    same = bool(np.array_equal(got[0], states[name[2:]]))
+                    rel = 0.0 if same else max(max_rel(got[0][:, :got[0].shape[1] // 2], states[name[2:]][:, :got[0].shape[1] // 2])[0],
+                                               max_rel(got[0][:, got[0].shape[1] // 2:], states[name[2:]][:, got[0].shape[1] // 2:])[0])
+                    reducing = self.symmetric or self.replicated
+                    v["vs_torch_loop"] = ("bit-identical" if same else
+                                          f"differs by {rel:.2e} (" + ("another order of the RCCL sum: accepted below 1e-6" if reducing and rel <= 1e-6
+                                                                       else "REJECTED: the same exchange must give the same bits") + ")")
+                    if not same and not (reducing and rel <= 1e-6):
+                        per_step = float("inf")
+                elif d == "c":
+                    v["vs_torch_loop"] = "no torch-driven trial of this protocol to compare with; judged on the unsharded check alone"
+                if np.isfinite(per_step):
+                    states[name] = got[0]
+            validation[name] = v
             self.close()
             return per_step
 
+        def cleanup(name: str) -> None:
+            self._broken = None
+            self.close()
+
         log = (lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush())) if self.plan.rank == 0 else None
-        prefer = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather")
+        prefer = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather", "auto")
+        failed: Dict[str, str] = {}
         best, job = time_candidates(list(cands), run_one, self.group, self.deadline_s, self.plan.rank,
-                                    prefer=prefer + tuple("c:" + k for k in prefer), log=log)
+                                    prefer=prefer + tuple("c:" + k for k in prefer), log=log, cleanup=cleanup, failed=failed)
         self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best,
-                       "order": list(cands), "deadline_s_per_candidate": self.deadline_s}
+                       "order": list(cands), "deadline_s_per_candidate": self.deadline_s,
+                       "validation": {k: {a: b for a, b in v.items() if a in ("max_rel_pos", "max_rel_vel", "steps", "ok", "vs_torch_loop", "replicas", "error")}
+                                      for k, v in validation.items()},
+                       "failed": failed,
+                       "validated_against": (f"one unsharded handle on rank 0, {trial_steps} steps, tolerance {PARITY_TOL:g}" if self.verify else None)}
         return cands[best]
 
     def replicas_identical(self) -> bool:
@@ -515,6 +712,18 @@ class DistributedSimulation:
             ev.record(self.stream)
             marks.append(ev)
 
+    def _compute(self, call, *args) -> None:
+        """One compute call of the torch-driven loop.  After the first failure the rank stops computing but ``step`` KEEPS
+        ISSUING ITS COLLECTIVES (same kinds, same counts): the peers of a rank whose launch failed are then not left
+        inside a collective that never completes — they finish their steps (with this rank's garbage), and the failure
+        surfaces on this rank at the next ``wait()``, where a host can let the ranks agree on it (``time_candidates``)."""
+        if self._broken is not None:
+            return
+        try:
+            call(*args)
+        except L.NBodyError as e:
+            self._broken = e
+
     def step(self, dt: Optional[float] = None) -> None:
         """One sharded step; only enqueues (no host sync)."""
         if self.comm is not None:
@@ -528,11 +737,11 @@ class DistributedSimulation:
         if self.replicated:
             with self.torch.cuda.stream(self.stream):
                 self._mark(marks)
-                self.sim.step_begin(dt)      # all my pairs -> partial acceleration of every particle
+                self._compute(self.sim.step_begin, dt)   # all my pairs -> partial acceleration of every particle
                 self._mark(marks)
                 self.dist.all_reduce(self.acc_full, op=self.dist.ReduceOp.SUM, group=self.group)   # in place, same bits everywhere
                 self._mark(marks)
-                self.sim.step_finish()       # every rank kicks and drifts all n
+                self._compute(self.sim.step_finish)      # every rank kicks and drifts all n
                 self._mark(marks)
             self._host_enqueue_s += time.perf_counter() - t_host
             self._host_steps += 1
@@ -541,18 +750,18 @@ class DistributedSimulation:
             return
         with self.torch.cuda.stream(self.stream):
             self._mark(marks)
-            self.sim.step_begin(dt)          # pairs inside my own block / local j-block: overlaps the all-gather still in flight
+            self._compute(self.sim.step_begin, dt)   # pairs inside my own block / local j-block: overlaps the all-gather still in flight
             self._mark(marks)
             if self._pending is not None:
                 self._pending.wait()         # compute stream waits: every rank's new positions are in the CURRENT replica
                 self._pending = None
             self._mark(marks)
             if self.symmetric:
-                self.sim.step_mid()          # my run of the cross-block pairs -> partial acceleration of all n
+                self._compute(self.sim.step_mid)     # my run of the cross-block pairs -> partial acceleration of all n
                 self._mark(marks)
                 self._reduce_accelerations() # ordered after the force on this stream by the process group
                 self._mark(marks)
-            self.sim.step_finish()           # (all-gather protocol: remote j-blocks,) kick, drift -> NEXT becomes CURRENT
+            self._compute(self.sim.step_finish)      # (all-gather protocol: remote j-blocks,) kick, drift -> NEXT becomes CURRENT
             self._mark(marks)
             self._cur ^= 1
             self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
@@ -580,6 +789,9 @@ class DistributedSimulation:
                 self._pending.wait()
                 self._pending = None
         self.stream.synchronize()
+        if self._broken is not None:              # a compute call failed earlier; its collectives were still issued (_compute)
+            err, self._broken = self._broken, None
+            raise err
 
     # -- per-phase timing (HIP events on the compute stream) ----------------------
     def profile_phases(self, on: bool = True) -> None:
@@ -664,7 +876,10 @@ class DistributedSimulation:
 
     def close(self) -> None:
         if self.sim is not None:
-            self.wait()
+            try:
+                self.wait()
+            except L.NBodyError:                  # a failure already reported (or about to be, by the caller that closes)
+                pass
             if self.comm is not None:
                 self.comm.close()
                 self.comm = None

@@ -66,19 +66,20 @@ class Simulation:
         sym_chunk_pairs: int = 0,
         sym_tile: int = 0,
         pos_rows: int = 0,
-        pipeline: bool = False,
-        one_launch: bool = False,
         static_items: bool = False,
+        library=None,
     ):
         """The last arguments (from ``uniform_mass`` on) are ``nb_params.flags`` and the launch-geometry tuning fields
-        (0 / True = the library's automatic choice); the library reads no environment variables."""
-        lib = L.load()
+        (0 / True = the library's automatic choice); the library reads no environment variables.  ``library``: another
+        build of the library bound with ``_lib.bind`` (the tests' -DNB_TEST_HOOKS build); default the product."""
+        lib = library if library is not None else L.load()
         if bodies.dtype not in (L.BODY_DTYPE, L.BODY3_DTYPE):
             raise TypeError("bodies must be a numpy array of nbodysim_amd.BODY_DTYPE (64-byte Body records)")
         bodies = np.ascontiguousarray(bodies)
         view = L.BODY3_DTYPE if dims == 3 else L.BODY_DTYPE
         bodies = bodies.view(view)
-        p = L.default_params()
+        p = L.nb_params()
+        lib.nb_params_default(C.byref(p))
         p.eps = eps
         p.dt = SIMULATION_DT
         p.precision = {"fp32": L.NB_FP32, "fp64": L.NB_FP64}[precision]
@@ -98,7 +99,7 @@ class Simulation:
         p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
                    | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL) | (L.NB_FLAG_SHARD_ALLREDUCE if shard_allreduce else 0)
                    | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0) | (L.NB_FLAG_MASS_SCALING if mass_scaling else 0)
-                   | (L.NB_FLAG_PIPELINE if pipeline else 0) | (L.NB_FLAG_ONE_LAUNCH_STEP if one_launch else 0) | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
+                   | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail
@@ -113,7 +114,7 @@ class Simulation:
         self._params = p
         self._h = lib.nb_create(bodies.ctypes.data, bodies.shape[0], C.byref(p))
         if not self._h:
-            raise L.NBodyError("nb_create", L.last_error_code(), L.last_error())
+            raise L.NBodyError("nb_create", L.last_error_code(lib), L.last_error(lib))
         self.n = int(lib.nb_count(self._h))
         self.i_begin = int(lib.nb_owned_begin(self._h))
         self.i_count = int(lib.nb_owned_count(self._h))
@@ -127,71 +128,71 @@ class Simulation:
 
     def step(self, dt: Optional[float] = None) -> None:
         """``Simulation::step()``: one step, then ``bodies`` is coherent."""
-        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, 1))
+        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, 1), self._lib)
         self.sync()
 
     # -- throughput / build-defined surface ------------------------------------
     def advance(self, nsteps: int, dt: Optional[float] = None) -> None:
         """Enqueue nsteps steps; does not wait and does not refresh ``bodies``."""
-        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, nsteps))
+        L.check("nb_step", self._lib.nb_step(self._h, SIMULATION_DT if dt is None else dt, nsteps), self._lib)
 
     def wait(self) -> None:
-        L.check("nb_wait", self._lib.nb_wait(self._h))
+        L.check("nb_wait", self._lib.nb_wait(self._h), self._lib)
 
     def sync(self) -> np.ndarray:
-        L.check("nb_sync", self._lib.nb_sync(self._h, self.bodies.ctypes.data))
+        L.check("nb_sync", self._lib.nb_sync(self._h, self.bodies.ctypes.data), self._lib)
         return self.bodies
 
     def snapshot_begin(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Pipelined ``sync``: start copying the state as of the work enqueued so far into ``out`` (default:
         ``self.bodies``) and return at once; steps enqueued afterwards overlap the transfer.  Pair with ``snapshot_wait``."""
         out = self.bodies if out is None else out
-        L.check("nb_snapshot_begin", self._lib.nb_snapshot_begin(self._h, out.ctypes.data))
+        L.check("nb_snapshot_begin", self._lib.nb_snapshot_begin(self._h, out.ctypes.data), self._lib)
         return out
 
     def snapshot_wait(self) -> None:
-        L.check("nb_snapshot_wait", self._lib.nb_snapshot_wait(self._h))
+        L.check("nb_snapshot_wait", self._lib.nb_snapshot_wait(self._h), self._lib)
 
     def positions(self) -> np.ndarray:
         out = np.empty((self.i_count, 3 if self._params.dims == 3 else 2), dtype=np.float32)
-        L.check("nb_sync_positions", self._lib.nb_sync_positions(self._h, out.ctypes.data))
+        L.check("nb_sync_positions", self._lib.nb_sync_positions(self._h, out.ctypes.data), self._lib)
         return out
 
     def upload(self, bodies: np.ndarray) -> None:
         if bodies.dtype != L.BODY_DTYPE or bodies.shape[0] != self.n:
             raise ValueError("upload needs the n bodies of the whole system")
         bodies = np.ascontiguousarray(bodies)
-        L.check("nb_upload", self._lib.nb_upload(self._h, bodies.ctypes.data))
+        L.check("nb_upload", self._lib.nb_upload(self._h, bodies.ctypes.data), self._lib)
 
     def accelerations(self) -> np.ndarray:
         """Evaluate a(x) at the current positions (``attract()`` as a direct sum)."""
-        L.check("nb_accelerations", self._lib.nb_accelerations(self._h))
+        L.check("nb_accelerations", self._lib.nb_accelerations(self._h), self._lib)
         return self.sync()["acc"].copy()
 
     def energy(self) -> tuple:
         k, u = C.c_double(), C.c_double()
-        L.check("nb_energy", self._lib.nb_energy(self._h, C.byref(k), C.byref(u)))
+        L.check("nb_energy", self._lib.nb_energy(self._h, C.byref(k), C.byref(u)), self._lib)
         return k.value, u.value
 
     def momentum(self) -> tuple:
         """((px, py, pz), Lz): total linear momentum (``Body::momentum``, Body.hpp:103-106, summed; fp64 on the
         device) and angular momentum about the origin of the owned block."""
         p, lz = (C.c_double * 3)(), C.c_double()
-        L.check("nb_momentum", self._lib.nb_momentum(self._h, p, C.byref(lz)))
+        L.check("nb_momentum", self._lib.nb_momentum(self._h, p, C.byref(lz)), self._lib)
         return (p[0], p[1], p[2]), lz.value
 
     def dump(self, path: str) -> None:
-        L.check("nb_dump", self._lib.nb_dump(self._h, str(path).encode()))
+        L.check("nb_dump", self._lib.nb_dump(self._h, str(path).encode()), self._lib)
 
     # split step for sharded handles (SURVEY §8e)
     def step_begin(self, dt: Optional[float] = None) -> None:
-        L.check("nb_step_begin", self._lib.nb_step_begin(self._h, SIMULATION_DT if dt is None else dt))
+        L.check("nb_step_begin", self._lib.nb_step_begin(self._h, SIMULATION_DT if dt is None else dt), self._lib)
 
     def step_mid(self) -> None:
-        L.check("nb_step_mid", self._lib.nb_step_mid(self._h))
+        L.check("nb_step_mid", self._lib.nb_step_mid(self._h), self._lib)
 
     def step_finish(self) -> None:
-        L.check("nb_step_finish", self._lib.nb_step_finish(self._h))
+        L.check("nb_step_finish", self._lib.nb_step_finish(self._h), self._lib)
 
     def pos_buffer(self, which: int = L.NB_POS_CURRENT) -> int:
         return int(self._lib.nb_pos_buffer(self._h, which) or 0)
@@ -208,23 +209,23 @@ class Simulation:
         return int(self._lib.nb_stream(self._h) or 0)
 
     def profile(self, on: bool = True) -> None:
-        L.check("nb_profile_enable", self._lib.nb_profile_enable(self._h, int(on)))
+        L.check("nb_profile_enable", self._lib.nb_profile_enable(self._h, int(on)), self._lib)
 
     def profile_read(self, reset: bool = True) -> tuple:
         ms, cnt = C.c_double(), C.c_uint64()
-        L.check("nb_profile_read", self._lib.nb_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)))
+        L.check("nb_profile_read", self._lib.nb_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)), self._lib)
         return ms.value, int(cnt.value)
 
     def sym_info(self) -> dict:
         """Figures of the symmetric work plan (``nb_sym_plan_info``): items, chunks per item, slab bytes ..."""
         info = L.nb_sym_info()
         info.struct_size = C.sizeof(L.nb_sym_info)
-        L.check("nb_sym_plan_info", self._lib.nb_sym_plan_info(self._h, C.byref(info)))
+        L.check("nb_sym_plan_info", self._lib.nb_sym_plan_info(self._h, C.byref(info)), self._lib)
         return info.as_dict()
 
     def describe(self) -> str:
         buf = C.create_string_buffer(1024)
-        L.check("nb_describe", self._lib.nb_describe(self._h, buf, len(buf)))
+        L.check("nb_describe", self._lib.nb_describe(self._h, buf, len(buf)), self._lib)
         return buf.value.decode()
 
     def close(self) -> None:

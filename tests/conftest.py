@@ -14,6 +14,7 @@ GOLD = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "perf: orderings between measured durations (GPU box, -m perf); never part of the correctness suites")
 
 
 @pytest.fixture(scope="session")

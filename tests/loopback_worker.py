@@ -7,6 +7,7 @@ with the same handles driven through the library's in-process exchange (nb_excha
 """
 import ctypes as C
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -15,6 +16,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+# this whole process runs on the -DNB_TEST_HOOKS build (tests/libnbody_hip_testhooks.so): the product library has no
+# nb_debug_comm_transport and can load nothing but RCCL.  The binding takes the path from NBODY_HIP_LIB at its first load.
+import hooks  # noqa: E402
+os.environ["NBODY_HIP_LIB"] = str(hooks.HOOKS_PATH)
 import nbodysim_amd as nb  # noqa: E402
 from nbodysim_amd import _lib as L  # noqa: E402
 from nbodysim_amd.comm import Comm  # noqa: E402
@@ -123,6 +129,7 @@ def failure_case():
 
 def main():
     lib = nb.load()
+    lib.nb_debug_comm_transport.restype, lib.nb_debug_comm_transport.argtypes = hooks.DEBUG_PROTOTYPES["nb_debug_comm_transport"]
     L.check("nb_debug_comm_transport", lib.nb_debug_comm_transport(str(STUB).encode()))
     v = C.c_int()
     L.check("nb_comm_available", lib.nb_comm_available(C.byref(v)))

@@ -29,13 +29,35 @@ def test_header_and_binding_agree():
     assert set(syms) == set(L.PROTOTYPES), set(syms) ^ set(L.PROTOTYPES)
 
 
-def test_library_exports_every_declared_symbol():
+def dynamic_symbols(path):
+    """Every DEFINED symbol of the dynamic table of `path` (nm -D): what a process that loads the library can bind."""
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_library_exports_exactly_the_declared_c_abi():
+    """The product: the dynamic symbol table is the C ABI of include/nbody.h and NOTHING else — no test hook, no kernel
+    handle object, no planner internal, no C++ template instantiation (-fvisibility=hidden + nbodysim_amd/csrc/nbody.map)."""
     lib = C.CDLL(str(L.LIB_PATH))
     for name in declared_symbols():
         assert hasattr(lib, name), f"libnbody_hip.so lacks {name}"
-    out = subprocess.run(["nm", "-D", "--defined-only", str(L.LIB_PATH)], capture_output=True, text=True).stdout
-    exported = set(re.findall(r" T (nb_[a-z0-9_]+)", out))
-    assert set(declared_symbols()) <= exported
+    exported = dynamic_symbols(L.LIB_PATH)
+    assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+    assert not [s for s in exported if s.startswith("nb_debug")] and "nb_debug" not in HEADER
+
+
+def test_test_hooks_live_in_their_own_header_and_only_in_the_test_build():
+    """include/nbody_debug.h declares the nb_debug_* hooks; only the -DNB_TEST_HOOKS build (tests/libnbody_hip_testhooks.so)
+    has them; apart from them the two builds export the same ABI."""
+    import hooks
+    debug_header = (ROOT / "include" / "nbody_debug.h").read_text()
+    debug = set(re.findall(r"\b(nb_debug_[a-z0-9_]+)\s*\(", debug_header))
+    assert debug == set(hooks.DEBUG_PROTOTYPES) and len(debug) == 5
+    test_build = dynamic_symbols(hooks.HOOKS_PATH)
+    assert test_build == set(declared_symbols()) | debug
+    assert hooks.lib().nb_abi_version() == L.NB_ABI_VERSION
+    integration = (ROOT / "INTEGRATION.md").read_text()
+    assert "nb_debug_" not in integration                     # a maintainer binding the library never meets them
 
 
 def test_library_contains_gfx950_code_object():

@@ -44,18 +44,19 @@ def test_bench_line_contract():
     assert rf["kernel_instantiation"] == "nbk::force_sym_f32<0, 0, false, true>" and rf["pmc_status"] == "none" and rf["pmc_commit"] is None
     assert rf["valu_busy"] is None and abs(rf["arithmetic_intensity_flop_per_byte"] - 14.0 * 32768.0 ** 2 / rf["traffic"]) < 1e-6 * rf["arithmetic_intensity_flop_per_byte"]
     g = rf["general_mass"]
-    # individual masses: 12 + 2 ops per body instead of 10 + 2 — 14 % more VALU work; the 4 timed steps of this short run sit in the clock's
-    # ramp and the secondary is measured after them, so only a loose ordering is asserted (the headline-size comparison is in profiles/)
-    assert g["avg_launch_ms"] > 0.9 * rf["avg_launch_ms"] and 0 < g["frac"] < 1.1 * rf["frac"]
+    # individual masses: 12 + 2 ops per body instead of 10 + 2.  WHICH kernel ran is asserted (its template instantiation: MM_GENERAL = 1,
+    # mass-scaled = 2), never how long it took: durations are recorded fields; their ordering is a `-m perf` matter (tests/test_perf_order.py)
+    assert g["kernel_instantiation"] == "nbk::force_sym_f32<0, 1, false, true>" and g["avg_launch_ms"] > 0 and g["frac"] > 0
+    assert rf["frac_equal_masses"] == rf["frac"] and abs(rf["frac_individual_masses"] - g["frac"]) < 1e-12
     assert {"nproc", "affinity", "cgroup_cpus", "model"} <= set(d["cpu_baseline"]["host"])
     t = rf["one_sided_lds_tiled"]
-    assert t["kernel"] == "force_tiled_f32" and t["avg_launch_ms"] > rf["avg_launch_ms"] and 0.3 < t["frac"] < rf["frac"]
+    assert t["kernel"] == "force_tiled_f32" and t["kernel_instantiation"] is None and t["avg_launch_ms"] > 0 and t["frac"] > 0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     if cb["kind"] == "reference":     # the prebuilt oracle/_ref/libnbref.so travelled here: the reference's own loop, port beside it
-        assert cb["bitwise_equal_to_port"] is True and cb["port"]["value"] > cb["value"] > 0
+        assert cb["bitwise_equal_to_port"] is True and cb["port"]["value"] > 0 and cb["value"] > 0
     assert abs(d["energy"]["rel_drift"]) < 1e-3
     # burst vs settled: >= 2 s of steps AFTER the timed region, with their own clock / power samples; never part of `value`
     su = d["sustained"]
@@ -63,6 +64,7 @@ def test_bench_line_contract():
     assert abs(su["value"] - 32768.0 ** 2 * su["steps"] / su["seconds"]) < 1e-6 * su["value"]
     sc = rf["general_mass_scaled"]
     assert sc["mass_scaled"] is True and g["mass_scaled"] is False and sc["avg_launch_ms"] > 0
+    assert sc["kernel_instantiation"] == "nbk::force_sym_f32<0, 2, false, true>"
     if d["device_state"]:                       # hwmon files readable on this box
         assert {"at_start", "at_end", "sclk_mhz_mean", "power_w_mean"} <= set(d["device_state"])
 
@@ -96,6 +98,13 @@ def test_bench_line_of_a_two_rank_rehearsal():
     assert d["config"]["protocol"] in ("symmetric", "allreduce", "allgather") and d["config"]["backend"] == "gloo"
     t = d["config"]["protocol_tuning"]
     assert t["chosen"].startswith(d["config"]["protocol"]) and set(t["ms_per_step"]) == {"symmetric", "symmetric+late", "allreduce", "allgather"}
+    # self-validating: the sharded trajectory against ONE unsharded handle on rank 0, before and after the timed steps; every start-up
+    # candidate validated the same way; the plain all-gather configuration measured first and kept as the fallback line
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["steps"] == 1 and pc["max_rel_pos"] < 1e-5 and pc["max_rel_vel"] < 1e-5
+    assert pc["after_timed_region"]["ok"] is True and pc["after_timed_region"]["steps"] == 5
+    assert t["failed"] == {} and all(v["ok"] for v in t["validation"].values()) and set(t["validation"]) == set(t["ms_per_step"])
+    assert d["fallback"] == {"used": False} and d["config"]["safe_first"]["parity_check"]["ok"] is True and d["config"]["safe_first"]["ms_per_step"] > 0
     ph = d["phases_ms"]
     assert ph["rank0"]["steps"] == 4 and ph["max_over_ranks"]["stream_total"] > 0
     assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

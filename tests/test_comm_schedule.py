@@ -10,6 +10,7 @@ all-gather of step k beside the local force of step k + 1) are both asserted."""
 import numpy as np
 import pytest
 
+import hooks
 from nbodysim_amd import _lib as L
 
 N, WORLD, RPE = 65536, 2, 2
@@ -18,8 +19,8 @@ COMPUTE, COMM = 0, 1
 
 
 def three_steps(protocol, handles):
-    first = L.comm_schedule(protocol, handles, BLOCK, FULL, False)
-    steady = L.comm_schedule(protocol, handles, BLOCK, FULL, True)
+    first = hooks.comm_schedule(protocol, handles, BLOCK, FULL, False)
+    steady = hooks.comm_schedule(protocol, handles, BLOCK, FULL, True)
     ops = []
     for k, sched in enumerate((first, steady, steady)):
         for o in sched:
@@ -129,7 +130,7 @@ def test_allreduce_protocol_order(handles):
 
 
 def test_bad_arguments_are_refused():
-    lib = L.load()
+    lib = hooks.lib()
     import ctypes as C
     cnt = C.c_size_t()
     assert lib.nb_debug_comm_schedule(9, 1, 1, 1, 0, None, 0, C.byref(cnt)) == L.NB_EINVAL

@@ -114,7 +114,9 @@ def _sym_worker(rank, world, port, n, steps, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nbodysim_amd import _lib as L
-        items, info = L.sym_plan(n, 256, rank, world)
+        sys.path.insert(0, str(ROOT / "tests"))
+        import hooks
+        items, info = hooks.sym_plan(n, 256, rank, world)
         slab_r = np.zeros((info["slab_r_bytes"] // 8, 2))          # the travelling slab, laid out as the planner says
         ic = nb.plummer_2d(n, 11)
         m = ic["mass"].astype(np.float64)
@@ -236,10 +238,12 @@ def _allreduce_worker(rank, world, port, n, steps, out_dir):
 
     import nbodysim_amd as nb
     from nbodysim_amd import _lib as L
+    sys.path.insert(0, str(ROOT / "tests"))
+    import hooks
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        items, info = L.sym_plan(n, 256, rank, world)
+        items, info = hooks.sym_plan(n, 256, rank, world)
         ic = nb.plummer_2d(n, 11)
         m = ic["mass"].astype(np.float64)
         eps2, dt = 0.05 ** 2, 1e-3

@@ -79,13 +79,14 @@ def test_the_ticket_counters_wrap_around_2_to_the_32():
     launches draw ~2 700 items each steps across it; same bits as static items."""
     n = 65536
     ic = nb.plummer_2d(n, 11)
-    lib = nb.load()
-    with nb.Simulation(ic, eps=0.02, static_items=True) as s:
+    import hooks
+    lib = hooks.lib()                                        # the -DNB_TEST_HOOKS build: the product has no nb_debug_ticket_seed
+    with nb.Simulation(ic, eps=0.02, static_items=True) as s:      # the product library, static items
         s.advance(6, 1e-3)
         want = s.sync().copy()
-    with nb.Simulation(ic, eps=0.02) as s:
+    with nb.Simulation(ic, eps=0.02, library=lib) as s:
         assert s.sym_info()["items"] > 2000
-        L.check("nb_debug_ticket_seed", lib.nb_debug_ticket_seed(s._h, 2 ** 32 - 1000))
+        hooks.check("nb_debug_ticket_seed", lib.nb_debug_ticket_seed(s._h, 2 ** 32 - 1000))
         s.advance(6, 1e-3)
         got = s.sync().copy()
     assert _same(got, want)

@@ -6,7 +6,12 @@
 * the number of steps — i.e. of collectives — a rank enqueues in bench.py's sustained stretch is a function of
   rank-independent inputs only (the round-3 hang: step counts sized from each rank's own clock);
 * the RCCL id of a file-based launch carries the launch's nonce: a stale file of a crashed run is ignored, not consumed
-  (nb_comm_id_publish / nb_comm_id_await).
+  (nb_comm_id_publish / nb_comm_id_await);
+* the first multi-GPU bench line cannot be lost and cannot be wrong silently (bench.run_sharded over gloo, world 2, with the
+  stand-in engine of tests/shard_standin.py): a candidate that RAISES on one rank is skipped by agreement and the run ends
+  with a line; a candidate that HANGS after the safe-first configuration was measured ends with THAT line and status 0; a
+  sharded trajectory that drifts from the unsharded one makes every rank exit 4 naming the check — unless a valid line was
+  already measured, which is then printed with `fallback` saying why.
 """
 import ctypes as C
 import importlib.util
@@ -212,3 +217,110 @@ def test_id_file_handshake_ignores_a_stale_file(tmp_path):
     assert "belongs to another launch" not in str(e.value)
     lib = nb.load()
     assert lib.nb_comm_id_publish(None, 1, old) == L.NB_EINVAL and lib.nb_comm_id_await(str(path).encode(), 1, None, 10) == L.NB_EINVAL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 4. the multi-rank bench line: un-losable, self-validating (bench.run_sharded with the stand-in engine, world 2, gloo)
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_bench(fault, extra_args=(), n=256, timeout=150):
+    import json
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, {t!r}); import shard_standin as s; "
+            "s.bench_worker({{rank}}, 2, {port}, {n}, {fault!r}, {extra!r})").format(t=str(TESTS), port=port, n=n, fault=fault, extra=tuple(extra_args))
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(rank=r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    lines = [[json.loads(l) for l in out.splitlines() if l.startswith("{")] for out, _ in outs]
+    return [p.returncode for p in procs], lines, [e for _, e in outs]
+
+
+def test_bench_line_carries_a_passing_parity_check_and_the_safe_first_figure():
+    rcs, lines, errs = _run_bench(None)
+    assert rcs == [0, 0], errs
+    assert len(lines[0]) == 1 and lines[1] == []                              # rank 0 prints the ONE line
+    d = lines[0][0]
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["steps"] == 2 and pc["tolerance"] == 1e-5 and 0 <= pc["max_rel_pos"] < 1e-5 and 0 <= pc["max_rel_vel"] < 1e-5
+    assert pc["after_timed_region"]["ok"] is True and pc["after_timed_region"]["steps"] == 5
+    assert d["fallback"] == {"used": False} and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2
+    sf = d["config"]["safe_first"]
+    assert sf["protocol"] == "allgather" and sf["driver"] == "torch" and sf["parity_check"]["ok"] is True and sf["ms_per_step"] > 0
+    assert d["config"]["protocol"] == "allreduce" and d["config"]["protocol_tuning"]["chosen"] == "allreduce"      # the stand-in's fastest
+
+
+def test_a_candidate_that_raises_on_one_rank_is_skipped_by_agreement_and_a_line_is_printed():
+    """one rank raises inside `allreduce` -> both ranks finish with `allgather`, a line is printed."""
+    rcs, lines, errs = _run_bench(("raise", "tune:allreduce", 1))
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    t = d["config"]["protocol_tuning"]
+    assert d["config"]["protocol"] == "allgather" and t["chosen"] == "allgather" and t["ms_per_step"]["allreduce"] is None
+    assert "allreduce" in t["failed"] and "symmetric" not in t["failed"]      # skipped by agreement vs merely not eligible
+    assert "[tune] rank 0: allreduce: unavailable (failed on another rank)" in errs[0]
+    assert "injected" in errs[1] or "RuntimeError" in errs[1]
+    assert d["parity_check"]["ok"] is True and d["fallback"]["used"] is False
+
+
+def test_a_wrong_candidate_cannot_win_the_start_up_timing():
+    rcs, lines, errs = _run_bench(("corrupt", "tune:allreduce", 1))
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    assert d["config"]["protocol"] == "allgather" and d["config"]["protocol_tuning"]["ms_per_step"]["allreduce"] is None
+    assert d["parity_check"]["ok"] is True
+
+
+def test_a_candidate_that_hangs_after_the_safe_measurement_costs_nothing_but_time():
+    t0 = time.time()
+    rcs, lines, errs = _run_bench(("hang", "tune:allreduce", 1))
+    assert rcs == [0, 0], errs                                                # status 0 on BOTH ranks: the launcher sees a completed run
+    assert len(lines[0]) == 1 and lines[1] == []
+    d = lines[0][0]
+    assert d["fallback"]["used"] is True and "timing the start-up candidate 'allreduce'" in d["fallback"]["why"]
+    assert d["config"]["protocol"] == "allgather" and d["config"]["driver"] == "torch" and d["parity_check"]["ok"] is True
+    assert d["value"] > 0 and d["steps"] == 3
+    assert all("deadline of 6 s expired while timing the start-up candidate 'allreduce'" in e for e in errs)
+    assert time.time() - t0 < 90
+
+
+def test_a_drifting_block_makes_every_rank_exit_non_zero_naming_the_check():
+    """a deliberately corrupted block makes both ranks exit non-zero naming the check."""
+    # forced protocol: no safe-first measurement, no tuning — the configuration that is wrong is the only one
+    rcs, lines, errs = _run_bench(("corrupt", "allgather/torch", 1), extra_args=("--protocol", "allgather", "--driver", "torch"))
+    assert rcs == [4, 4], errs
+    assert lines == [[], []]                                                  # no bench line on stdout
+    assert "parity_check failed (allgather protocol, torch loop, after the warm-up)" in errs[0] and "block of rank 1" in errs[0]
+    import json
+    diag = [json.loads(l) for l in errs[0].splitlines() if l.startswith("{")]
+    assert diag and diag[0]["parity_check"]["ok"] is False and diag[0]["parity_check"]["worst_rank"] == 1 and diag[0]["parity_check"]["max_rel_pos"] > 1e-5
+
+
+def test_a_wrong_final_configuration_falls_back_to_the_validated_safe_line():
+    rcs, lines, errs = _run_bench(("corrupt", "final", 0))
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    assert d["fallback"]["used"] is True and "parity_check failed" in d["fallback"]["why"] and d["config"]["protocol"] == "allgather"
+    assert d["parity_check"]["ok"] is True                                    # the printed line is the validated one
+    assert "parity_check failed (allreduce protocol, torch loop, after the warm-up)" in errs[0]
+
+
+def test_parity_helpers_alone():
+    sys.path.insert(0, str(ROOT))
+    from nbodysim_amd.dist import ShardPlan, compare_with_unsharded, gather_rows, max_rel, state_rows
+    a = np.array([[1.0, 0.0], [0.0, 2.0], [0.0, 0.0]])
+    b = a.copy()
+    b[1, 1] = 2.0 + 2e-5
+    r, k = max_rel(b, a)
+    assert k == 1 and abs(r - 1e-5) < 1e-12
+    b[2, 0] = np.nan
+    assert max_rel(b, a) == (np.inf, 2)                                       # a NaN is a failure, never a pass
+    plan = ShardPlan(3, 1, 0)
+    rows = np.concatenate([a, a], axis=1)
+    assert np.array_equal(gather_rows(rows, plan), rows)
+    ok = compare_with_unsharded(rows, plan, lambda: rows, 7)
+    assert ok["ok"] and ok["max_rel_pos"] == 0.0 and ok["steps"] == 7 and ok["error"] is None
+    bad = compare_with_unsharded(rows * (1 + 1e-4), plan, lambda: rows, 7)
+    assert not bad["ok"] and bad["worst_rank"] == 0
+    boom = compare_with_unsharded(rows, plan, lambda: 1 / 0, 7)
+    assert not boom["ok"] and "ZeroDivisionError" in boom["error"]
+    rec = np.zeros(2, dtype=[("pos", np.float32, 2), ("vel", np.float32, 2)])
+    rec["pos"], rec["vel"] = [[1, 2], [3, 4]], [[5, 6], [7, 8]]
+    assert state_rows(rec).tolist() == [[1, 2, 5, 6], [3, 4, 7, 8]]

@@ -69,7 +69,8 @@ def test_device_fast_inv_sqrt_bit_exact_on_the_reference_golden_grid(gold):
     x = np.ascontiguousarray(gold["fast_inv_sqrt_x"], np.float32)
     want = np.ascontiguousarray(gold["fast_inv_sqrt_y"], np.float32)
     ys, yp = np.empty_like(x), np.empty_like(x)
-    L.check("nb_debug_fast_inv_sqrt", nb.load().nb_debug_fast_inv_sqrt(x.ctypes.data, ys.ctypes.data, yp.ctypes.data, x.size))
+    import hooks                                              # test build: the device forms of the product kernels, exposed on an array
+    hooks.check("nb_debug_fast_inv_sqrt", hooks.lib().nb_debug_fast_inv_sqrt(x.ctypes.data, ys.ctypes.data, yp.ctypes.data, x.size))
     assert x.size == 4096 and np.array_equal(bits(ys), bits(want)) and np.array_equal(bits(yp), bits(want))
 
 
@@ -333,6 +334,30 @@ def test_fp64_energy_drift_small(nbo):
     # same trajectory as the CPU fp64 direct sum => same energy to ~1e-10
     assert abs((k1 + u1) - (ke + ue)) < 1e-9 * abs(ke + ue)
     assert abs((k1 + u1 - k0 - u0) / (k0 + u0)) < 1e-3
+
+
+def test_config1_fp64_100_steps_as_written(gold, nbo):
+    """BASELINE.json configs[0] on the GPU exactly as written: N = 1 024 Plummer, fp64, 100 leapfrog steps — the whole
+    trajectory against the CPU fp64 direct sum (nbo.step_f64; Simulation.hpp:129-131,160-163 order), and the three
+    distances of SURVEY §8c re-measured with the GPU trajectory in FP64-DIRECT's place."""
+    flat = gold["ic_plummer_1024"]
+    with nb.Simulation(bodies_from_flat(flat), eps=EPS, precision="fp64") as sim:
+        sim.advance(100, DT)
+        k, u = sim.energy()
+        got = sim.sync().copy()
+        assert sim.frame == 100
+    d = nbo.step_f64(nbo.state_from_flat(flat, np.float64), f32(EPS), f32(DT), 100)
+    ke, ue = nbo.energy(d, f32(EPS))
+    pos64, vel64 = np.stack([d["x"], d["y"]], 1), np.stack([d["vx"], d["vy"]], 1)
+    # the state itself is fp64 on the device: its energy agrees with the CPU trajectory's to 1e-11 ...
+    assert abs((k + u) - (ke + ue)) < 1e-11 * abs(ke + ue)
+    # ... positions and velocities come back through the reference's float Body record: float output precision
+    assert max_rel(got["pos"], pos64) < 2e-7 and max_rel(got["vel"], vel64) < 2e-7
+    # the reference's own arithmetic (REF-DIRECT goldens, Quake rsqrt, fp32) sits where SURVEY §8c measured it from fp64
+    q = gold["ref_direct_s100"]
+    assert 1e-5 < max_rel(q[:, 0:2], got["pos"]) < 1e-3 and 1e-4 < max_rel(q[:, 2:4], got["vel"]) < 5e-2
+    # and the production Barnes-Hut step (REF-STEP) ~1e-2 away
+    assert 1e-3 < max_rel(gold["ref_step_s100"][:, 0:2], got["pos"]) < 1e-1
 
 
 # --------------------------------------------------------------- sharding ---

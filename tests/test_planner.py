@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import hooks
 import nbodysim_amd as nb
 from nbodysim_amd import _lib as L
 
@@ -18,10 +19,10 @@ SB, CH = 2048, 64
 def plan(n, rank, world, cus=256, **tuning):
     p = None
     if tuning:
-        p = L.default_params()
+        p = hooks.default_params()
         for k, v in tuning.items():
             setattr(p, k, v)
-    items, info = L.sym_plan(n, cus, rank, world, p)
+    items, info = hooks.sym_plan(n, cus, rank, world, p)
     return items, info
 
 
@@ -153,7 +154,7 @@ def test_plan_fills_the_chip():
 
 
 def test_plan_rejects_bad_arguments():
-    lib = nb.load()
+    lib = hooks.lib()
     info = L.nb_sym_info()
     info.struct_size = C.sizeof(L.nb_sym_info)
     assert lib.nb_debug_sym_plan(0, 256, 0, 1, None, None, 0, C.byref(info)) == L.NB_EINVAL
