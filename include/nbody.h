@@ -380,7 +380,9 @@ int   nb_shard_rank(const nb_sim *s, int *world);   /* nb_params.shard_rank (and
  * other means.  If a call fails half-way through a step (a HIP or RCCL error), the run cannot be continued: the communicator is
  * marked failed (an open ncclGroup is closed, further nb_comm_step / _flush / _wait return NB_ESTATE) and nb_comm_destroy
  * then ABORTS the RCCL communicator (ncclCommAbort) instead of synchronising with peers that may never arrive; destroy the
- * communicator and the handles. */
+ * communicator and the handles.  A FAILED communicator leaks on purpose what could block if released: its communication
+ * stream always, and the RCCL communicator itself where the transport has no ncclCommAbort (ncclCommDestroy may wait for
+ * the very peers that never arrived). */
 typedef struct nb_comm nb_comm;
 #define NB_COMM_ID_BYTES 128
 int      nb_comm_unique_id(void *id_out /* NB_COMM_ID_BYTES */);

@@ -111,6 +111,7 @@ struct nb_sim {
     SymCov *sym_cov_dev = nullptr;             // coverage entries: main lists, then (from sym_cov_late_off) the late ones
     nb_sym_info sym_info{};
     void *sym_slab_s = nullptr, *sym_slab_r = nullptr;       // float2 / double2 by precision
+    bool broken = false;                       // a force launch was refused by the runtime: every later step returns NB_ESTATE
     // dynamic item tickets of the whole-system symmetric launch (sym_item_index, nb_kernels.hip.h)
     uint32_t *sym_ticket = nullptr;            // device: one counter on a line of its own, monotonic modulo 2^32
     uint32_t sym_ticket_base[3] = {0, 0, 0};   // what the launches so far have drawn, per launch kind (local or whole | cross | late: one counter each,
@@ -233,7 +234,6 @@ static bool needs_guard(const nb_sim *s) { return s->fp64 ? !(s->p.eps > 0.0f) :
 // workload), -2.5 % at 16 384 and 32 768, neutral at 65 536, +1.3 ... +2.6 % at 131 072: used below 49 152 bodies.
 // fp32 2-D, single handle (a rank of a sharded run keeps the classic tiles: its blocks are whole 2048-particle tiles).
 // nb_params.sym_tile = 512 / 2048 forces one.  Rank-independent (n and parameters only).
-constexpr size_t SYM_WS_MAX_N = 49152;
 static uint32_t sym_tile_of(const nb_params &p, size_t n)
 {
     if (p.precision == NB_FP64 || p.dims == 3 || p.shard_world > 1 || (p.flags & NB_FLAG_SHARD_SINGLE)) return SYM_SB;
@@ -873,7 +873,7 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
     const uint32_t slot = first == 0 ? 0u : (first == s->sym_items_local ? 1u : 2u);
     const bool dyn = s->sym_ticket != nullptr && !(s->p.flags & NB_FLAG_STATIC_ITEMS);
     uint32_t *tk = nullptr;
-    uint32_t fw = 0, tb = 0;
+    uint32_t fw = 0, tb = 0, drawn = 0;      // drawn: tickets this launch will take — committed to the host's record only once the launch is known to be enqueued
 #define NB_TICKETS(KERNEL)                                                                                                        \
     do {                                                                                                                          \
         if (dyn) {                                                                                                                \
@@ -884,7 +884,7 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
             }                                                                                                                     \
             fw = s->sym_first_wave < count ? s->sym_first_wave : count;                                                           \
             tk = s->sym_ticket + slot * 32u; tb = s->sym_ticket_base[slot];                                                       \
-            s->sym_ticket_base[slot] += count - fw;                                                                               \
+            drawn = count - fw;                                                                                                   \
         }                                                                                                                         \
     } while (0)
     if (s->dims3 && s->fp64) {
@@ -942,7 +942,17 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
 #undef NB_SYM_GO
     }
 #undef NB_TICKETS
-    HIPCHK(hipGetLastError());
+    {
+        // The host's record of the tickets advances only with a launch that was accepted: if this one was refused, the device
+        // counter did not move either, but a kernel of an EARLIER launch may still be drawing — nothing sound can follow on
+        // this handle, so it is refused from here on (nb_step_begin) instead of indexing items[] with a base that may be off.
+        const hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            s->broken = true;
+            return nb_fail(hip_code(e_), "launch of the symmetric force kernel failed: %s; the handle is unusable from here on", hipGetErrorString(e_));
+        }
+        s->sym_ticket_base[slot] += drawn;
+    }
     if (s->prof && prof_end(s, pr, st)) return NB_EHIP;
     return NB_OK;
 }
@@ -1180,6 +1190,7 @@ extern "C" int nb_step_begin(nb_sim *s, float dt)
 {
     if (!s) return nb_fail(NB_EINVAL, "nb_step_begin: NULL handle");
     if (s->in_step) return nb_fail(NB_ESTATE, "nb_step_begin: previous step not finished");
+    if (s->broken) return nb_fail(NB_ESTATE, "nb_step_begin: an earlier force launch of this handle was refused by the runtime; destroy the handle");
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT) return nb_fail(NB_EINVAL, "nb_step_begin: split stepping is the kick-drift integrator's (a KDK handle steps with nb_step)");
     if (bind(s)) return NB_EHIP;
     s->pending_dt = dt > 0.0f ? dt : s->p.dt;

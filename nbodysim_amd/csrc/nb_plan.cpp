@@ -113,7 +113,10 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // 32 768 / 36 000; two sizes lose 2-4 % to a plan of 8 chunks per item (12 288, 16 384).  Beyond ~25 items per CU the count no
     // longer quantises and the per-item costs show: from there 8 chunks per item with the late tail (40 000 ... 49 151: -1 ... -2 %).
     bool no_tail = false, late_tail = false;
-    if (!tune.forced_L && !tune.tail_given && world == 1 && g.sb == SYM_SB_WS && tune.guided_tail) {
+    // The rule was measured below SYM_WS_MAX_N bodies only, where the library itself chooses such tiles; a tile of 512 FORCED at a
+    // large n (nb_params.sym_tile) keeps the size-derived L above — one or two chunks per wave there would mean ~65 000 items and
+    // half a GiB of travelling partials at N = 262 144.
+    if (!tune.forced_L && !tune.tail_given && world == 1 && g.sb == SYM_SB_WS && tune.guided_tail && n < SYM_WS_MAX_N) {
         uint64_t items = 0;
         for (uint32_t I = 0; I < tiles; ++I) {
             const uint32_t d0 = I * g.cpt, dend = g.diag_end(I);

@@ -17,6 +17,7 @@ namespace nbk {
 constexpr uint32_t SYM_SB = 2048;   // stationary particles per workgroup / block-tile (4 waves x 512 different particles)
 constexpr uint32_t SYM_SB_WS = 512; // block-tile of the WAVE-SPLIT kernels (small and mid-size systems): the 4 waves of a workgroup
                                     // hold the SAME 512 stationary particles and sweep DIFFERENT chunks of the item
+constexpr uint32_t SYM_WS_MAX_N = 49152; // whole systems below this many bodies get wave-split tiles by default; the planner's rules for such tiles hold below it only
 constexpr uint32_t SYM_CH = 64;     // travelling chunk (one particle per lane of a wave64)
 
 // One workgroup of force_sym_*: tile `tile` (SymPlan::sb particles) against chunks [c0, c0 + cnt).

@@ -197,6 +197,13 @@ def test_small_system_plans_follow_the_measured_rules():
     # an explicit item size or explicit thresholds are taken as given
     items, info = plan(25000, 0, 1, sym_chunks_per_item=8)
     assert info["chunks_per_item"] == 8
+    # the fine-item rule holds where it was measured (below 49 152 bodies): tiles of 512 FORCED at the headline size keep the
+    # size-derived item length (a multiple of the wave quantum), not 8-16 chunks — ~65 000 items and 0.5 GiB of partials
+    items, info = plan(262144, 0, 1, sym_tile=512)
+    assert info["tile_particles"] == 512 and info["chunks_per_item"] >= 32 and info["chunks_per_item"] % 8 == 0
+    assert len(items) < 12000              # (the 0.5 GiB of travelling partials is the price of 512 tiles of 512 at this n, whatever the item length)
+    items64, info64 = plan(65536, 0, 1, sym_tile=512)
+    assert info64["chunks_per_item"] >= 8 and len(items64) < 12000
     # classic tiles (fp64 handles): late tail below 1.5 rounds of workgroups, early tail between 1.5 and 5
     p = dict(precision=L.NB_FP64)
     late16, _ = plan(16384, 0, 1, **p)
