@@ -196,7 +196,7 @@ def kernel_instantiation(desc, precision, dims, rsqrt):
     """The exact template instantiation of the dominant force kernel as rocprofv3 prints it, from nb_describe's fields —
     what a PMC record must name to be THIS run's kernel (None for the kernels no PMC set is kept for)."""
     f = dict(kv.split("=", 1) for kv in desc.replace("|", " ").split() if "=" in kv)
-    if precision != "fp32" or dims != 2 or f.get("symmetric") != "1" or f.get("pipeline") == "1":
+    if precision != "fp32" or dims != 2 or f.get("symmetric") != "1":
         return None
     mm = 0 if f.get("uniform_mass") == "1" else 2 if f.get("mass_scaled") == "1" else 1
     b = lambda v: "true" if v else "false"
@@ -419,7 +419,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     """The ONE JSON line (rank 0) from a timed region's measurement `m` (timed_region) of `sim`."""
     inner = sim.sim if world > 1 else sim
     secondary = secondary or {}
-    general, scaled, lds_tiled = secondary.get("general"), secondary.get("scaled"), secondary.get("lds_tiled")
+    general, scaled, lds_tiled, auto = secondary.get("general"), secondary.get("scaled"), secondary.get("lds_tiled"), secondary.get("auto")
     elapsed, force_ms, launches = m["elapsed"], m["force_ms"], m["launches"]
     k0, u0, k1, u1 = m["energy"]
     flop_per_pair = FLOP_PER_PAIR if args.dims == 2 else 20.0   # 3-D: one more sub, fma, fma per pair side (SURVEY §8f-4)
@@ -523,6 +523,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             # reference's own bodies (Simulation.hpp:565-577) do not
             "frac_equal_masses": (achieved / peak) if (um and world == 1) else None,
             "frac_individual_masses": ((achieved / peak) if (not um and world == 1) else (frac_of(general["avg_launch_ms"]) if general else None)),
+            "frac_individual_masses_default": (frac_of(auto["avg_launch_ms"]) if auto else None),
             "executed_tflops": executed,
             "executed_frac": executed / peak if executed else None,
             "executed_flop_per_unordered_pair": ex["sym"][0 if um else 1] if symmetric else None,
@@ -549,9 +550,13 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
                                       "body): untimed secondary run"}
                              if general else None),
             "general_mass_scaled": ({**scaled, "frac": frac_of(scaled["avg_launch_ms"]),
-                                     "note": "NB_FLAG_MASS_SCALING: masses folded into the pair geometry (11 + 2 per body); taken by default only "
-                                             "where the upload-time rule finds its extra rounding harmless (DESIGN.md §4.1)"}
+                                     "note": "NB_FLAG_MASS_SCALING forced: masses folded into the pair geometry (11 + 2 per body); by default the library "
+                                             "takes this body only where its upload-time measurement finds the extra rounding harmless (DESIGN.md §4.1)"}
                                     if scaled else None),
+            "general_mass_default": ({**auto, "frac": frac_of(auto["avg_launch_ms"]),
+                                      "note": "individual masses with neither mass-scaling flag: the library compares the two bodies on the uploaded data "
+                                              "(two force evaluations) and folds the masses only if the accelerations agree to 2e-6 of the force scale"}
+                                     if auto else None),
             "one_sided_lds_tiled": ({**lds_tiled, "kernel": "force_tiled" + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64"),
                                      "frac": frac_of(lds_tiled["avg_launch_ms"]),
                                      "note": "north_star's kernel design (every ordered pair, j-tiles of 256 in LDS) on the same workload: untimed secondary run"}
@@ -620,7 +625,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
         if state["safe_line"] is None:
             return None
         line = dict(state["safe_line"])
-        line["fallback"] = {"used": True, "why": msg, "phase": phase["now"]}
+        line["fallback"] = {"used": True, "why": msg, "phase": phase["now"], "protocol_tuning": state.get("tuning")}
         print_once(line)
         return 0
 
@@ -653,6 +658,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
                     sim = None
         phase["now"] = f"creating the sharded simulation (protocol {args.protocol}, driver {args.driver})"
         sim = make_sim("allgather" if args.no_symmetry else args.protocol, args.driver)
+        state["tuning"] = getattr(sim, "tuning", None)        # what the start-up timing found, for the fallback line too
         m = timed_region(sim, args, world, rank, barrier, device_sync, reference, phase, "", check)
         sustained = None
         if not args.no_sustained:
@@ -681,7 +687,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             sys.stderr.write(f"[bench] {e}\n")
         if state["safe_line"] is not None:
             line = dict(state["safe_line"])
-            line["fallback"] = {"used": True, "why": str(e), "phase": phase["now"]}
+            line["fallback"] = {"used": True, "why": str(e), "phase": phase["now"], "protocol_tuning": state.get("tuning")}
             print_once(line)
         else:
             if rank == 0:
@@ -694,7 +700,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             raise
         sys.stderr.write(f"[bench] rank {rank}: {type(e).__name__}: {e} (phase: {phase['now']}); printing the safe-first line\n")
         line = dict(state["safe_line"])
-        line["fallback"] = {"used": True, "why": f"{type(e).__name__}: {e}", "phase": phase["now"]}
+        line["fallback"] = {"used": True, "why": f"{type(e).__name__}: {e}", "phase": phase["now"], "protocol_tuning": state.get("tuning")}
         print_once(line)
     finally:
         phase["now"] = "closing"
@@ -808,13 +814,16 @@ def main() -> None:
                 g.wait()
                 gms, gl = g.profile_read()
                 desc = g.describe()
+            check = [kv.split("=", 1)[1] for kv in desc.replace("|", " ").split() if kv.startswith("mass_scaling_check=")]
             return {"avg_launch_ms": gms / gl, "launches": gl, "mass_scaled": "mass_scaled=1" in desc,
+                    "mass_scaling_check": float(check[0]) if check and float(check[0]) >= 0 else None,
                     "kernel_instantiation": kernel_instantiation(desc, args.precision, args.dims, args.rsqrt)}
         if not args.general_mass:
             # the same kernel without the equal-mass specialisation (12 + 2 instead of 10 + 2 instructions per body): what a system with
             # individual masses — the reference's own bodies, Simulation.hpp:565-577 — gets
-            secondary["general"] = second(uniform_mass=False)
-            secondary["scaled"] = second(uniform_mass=False, mass_scaling=True)   # NB_FLAG_MASS_SCALING forced: masses folded into the pair geometry (11 + 2)
+            secondary["general"] = second(uniform_mass=False, mass_scaling=False)  # NB_FLAG_NO_MASS_SCALING: both per-pair mass multiplies (12 + 2)
+            secondary["scaled"] = second(uniform_mass=False, mass_scaling=True)    # NB_FLAG_MASS_SCALING forced: masses folded into the pair geometry (11 + 2)
+            secondary["auto"] = second(uniform_mass=False)                         # the default: the library measures at upload which of the two this data gets
         if not args.no_symmetry:
             # north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of 256 — on the same workload
             secondary["lds_tiled"] = second(steps=max(4, args.steps // 4), symmetry=False, uniform_mass=not args.general_mass)

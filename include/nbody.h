@@ -110,16 +110,17 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
        NB_FLAG_MASS_SCALING    = 32,  /* individual masses, fp32, exact rsqrt, tiled sum, eps > 0: fold the masses into the pair
                                          geometry (nb_kernels.hip.h MM_SCALED: the travelling particle carries m^(-1/2) and its
                                          pre-multiplied position, one multiply less per pair in the symmetric kernel, none at all
-                                         in the one-sided one).  OFF by default: the pair displacement is then no longer an exact
-                                         difference of two floats (relative error 6e-8 |x| / |d| per pair force), which a broad
-                                         mass spectrum with close heavy pairs turns into 6e-5 of the force scale (measured,
-                                         tests/test_headline_gpu.py) for 2.5 % of kernel time.  Needs m > 0 everywhere and
-                                         m_max^(3/2) / eps^3 inside the float range, else the flag is ignored (nb_describe tells).
-                                         SELF TERM: with the masses in the geometry a body's pair with ITSELF no longer cancels exactly
-                                         (its displacement is the rounding residue of sigma x, not 0): every body gets a spurious
-                                         acceleration of up to 6e-8 |x| m / eps^3 — 0.06 |x| m at eps = 0.01, growing as eps^-3 — and the
-                                         total momentum is conserved to that level only, not to rounding (measured in
-                                         tests/test_headline_gpu.py); one more reason the flag is opt-in */
+                                         in the one-sided one: 2.5 % of kernel time).  The pair displacement is then no longer an exact
+                                         difference of two floats (relative error 6e-8 |x_j| / |d| per pair force), and a body's pair with
+                                         ITSELF no longer cancels exactly (a spurious self-acceleration of up to 6e-8 |x| m / eps^3; total
+                                         momentum is conserved to that level only) — harmless for light, similar masses, several 1e-5 of the
+                                         force scale for a broad mass spectrum with close heavy pairs (tests/test_headline_gpu.py).
+                                         DEFAULT (neither this bit nor the next): the library MEASURES it at nb_create / nb_upload of an
+                                         unsharded handle — the uploaded bodies' accelerations with and without the folding, two force
+                                         evaluations — and folds only if they agree to 2e-6 of the force scale (nb_describe:
+                                         mass_scaled, mass_scaling_check).  THIS BIT: fold wherever representable (m > 0 everywhere,
+                                         m_max^(3/2) / eps^3 inside the float range), whatever the data; sharded handles fold only so */
+       NB_FLAG_NO_MASS_SCALING = 512, /* never fold: both per-pair mass multiplies stay (12 + 2 instructions per body) */
        /* 64 and 128 were NB_FLAG_PIPELINE / NB_FLAG_ONE_LAUNCH_STEP of ABI 4: two in-launch fusions of the step (a persistent step
           pipeline, one launch per step) that measured level or slower than two launches per step (docs/rounds/r04.md) and were removed
           in ABI 5 — nb_create rejects the bits like any unknown one */

@@ -30,6 +30,7 @@ NB_POS_CURRENT, NB_POS_NEXT = 0, 1
 NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1, 2, 3
 NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE, NB_FLAG_SHARD_SINGLE, NB_FLAG_MASS_SCALING = 1, 2, 4, 8, 16, 32
 NB_FLAG_STATIC_ITEMS = 256
+NB_FLAG_NO_MASS_SCALING = 512
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(

@@ -99,6 +99,7 @@ struct nb_sim {
     bool sym_pairs = false;         // symmetric fp32 kernel sweeps chunk pairs (want_pairs)
     bool mass_scaled = false;       // individual masses folded into the pair geometry (MM_SCALED, nb_kernels.hip.h)
     float *sigma = nullptr;         // m^(-1/2) per particle, for mass_scaled
+    float mass_scaling_dev = -1.0f; // what the upload-time check measured: max |a_scaled - a_general| / max |a_general| (-1: not measured)
 
     // symmetric path (force_sym_f32): work items and its two slab sets
     bool sym = false;
@@ -593,6 +594,63 @@ static void free_all(nb_sim *s)
     delete s;
 }
 
+static int launch_force(nb_sim *s, const ForceJob &j);
+static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double dt_drift, int flags);
+
+// The automatic rule of the mass-scaled body: decided per upload FROM THE DATA, by measurement.  The
+// accelerations of the uploaded bodies are evaluated twice — with the per-pair mass multiplies (MM_GENERAL) and with the masses
+// folded into the pair geometry (MM_SCALED) — and the scaled body is taken only if the two agree to MASS_SCALING_TOL of the
+// force scale (max |a|): 2e-6, a fifth of north_star's 1e-5.  That covers everything the extra rounding depends on — the mass
+// spectrum, how close heavy pairs sit, how far from the origin the system is, the self term — without a model of any of it.
+// Equal-ish light masses pass (Plummer spheres: ~1e-7, the two bodies' ordinary rounding difference); the reference's own bodies
+// pass (Simulation.hpp:347-603: the 1e9 central mass sits AT the origin, where sigma x = 0 is exact, and dominates every
+// force); a four-decade mixture with close heavy pairs does not (6e-5: tests/test_headline_gpu.py) and keeps MM_GENERAL.
+// Cost: two force evaluations per upload (14 ms at N = 262 144).  The verdict holds for the configuration uploaded; a host
+// whose bodies will later form heavy close pairs far from the origin sets NB_FLAG_NO_MASS_SCALING.
+constexpr float MASS_SCALING_TOL = 2e-6f;
+static int choose_mass_scaling(nb_sim *s)
+{
+    const size_t bytes = s->i_count * s->esz;
+    const uint32_t n = (uint32_t)s->i_count;
+    void *saved = nullptr, *ref = nullptr;
+    uint32_t *out = nullptr;
+    int rc = NB_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&saved, bytes));
+        HIPCHK(hipMalloc(&ref, bytes));
+        HIPCHK(hipMalloc((void **)&out, 2 * sizeof(uint32_t)));
+        HIPCHK(hipMemcpyAsync(saved, s->acc, bytes, hipMemcpyDeviceToDevice, s->stream));      // the uploaded acc field survives the check
+        HIPCHK(hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), s->stream));
+        int r;
+        s->mass_scaled = false;
+        if ((r = launch_force(s, s->job_all)) || (r = launch_integrate(s, s->slabs_all, 0.0, 0.0, 0))) return r;
+        HIPCHK(hipMemcpyAsync(ref, s->acc, bytes, hipMemcpyDeviceToDevice, s->stream));
+        s->mass_scaled = true;
+        if ((r = launch_force(s, s->job_all)) || (r = launch_integrate(s, s->slabs_all, 0.0, 0.0, 0))) return r;
+        max_deviation_f32<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, s->stream>>>((const float2 *)s->acc, (const float2 *)ref, n, out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->acc, saved, bytes, hipMemcpyDeviceToDevice, s->stream));
+        uint32_t *host = nullptr;
+        HIPCHK(hipHostMalloc((void **)&host, 2 * sizeof(uint32_t), hipHostMallocDefault));
+        hipError_t e = hipMemcpyAsync(host, out, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        float dev = 0.f, scale = 0.f;
+        memcpy(&dev, &host[0], sizeof dev);
+        memcpy(&scale, &host[1], sizeof scale);
+        (void)hipHostFree(host);
+        if (e != hipSuccess) return nb_fail(hip_code(e), "nb_upload: mass-scaling check: %s", hipGetErrorString(e));
+        const bool comparable = dev == dev && scale == scale && scale > 0.f && scale < 3.0e38f;
+        s->mass_scaling_dev = comparable ? dev / scale : HUGE_VALF;
+        s->mass_scaled = comparable && dev <= MASS_SCALING_TOL * scale;
+        return NB_OK;
+    };
+    rc = body();
+    if (rc) s->mass_scaled = false;
+    (void)hipFree(saved); (void)hipFree(ref); (void)hipFree(out);
+    s->acc_valid = false;
+    return rc;
+}
+
 static int do_upload(nb_sim *s, const nb_body *in)
 {
     // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
@@ -601,13 +659,18 @@ static int do_upload(nb_sim *s, const nb_body *in)
     for (size_t i = 1; s->uniform_mass && i < s->n; ++i)
         if (memcmp(&in[i].mass, &in[0].mass, sizeof(float)) != 0) s->uniform_mass = false;
     s->um_mass = in[0].mass;
-    // NB_FLAG_MASS_SCALING (opt-in): individual masses folded into the pair geometry (MM_SCALED: 11 + 2 instead of 12 + 2
-    // instructions per body of the symmetric kernel, 8 + 2 instead of 9 + 2 in the one-sided one) when every mass is
-    // positive and sigma = m^(-1/2), sigma * (the kernels' padding coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all
-    // stay finite floats with room to spare.  Exact rsqrt only: the Quake mode keeps the reference's arithmetic.
+    // Mass scaling: individual masses folded into the pair geometry (MM_SCALED: 11 + 2 instead of 12 + 2 instructions per body of
+    // the symmetric kernel, 8 + 2 instead of 9 + 2 in the one-sided one).  REPRESENTABLE when every mass is positive and
+    // sigma = m^(-1/2), sigma * (the kernels' padding coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all stay finite floats
+    // with room to spare; exact rsqrt only (the Quake mode keeps the reference's arithmetic).  Whether it is also HARMLESS — its
+    // displacement is rounded once more, 6e-8 |x_j| / |d| per pair force, which heavy close pairs turn into several 1e-5 of the
+    // force scale — depends on the data: NB_FLAG_MASS_SCALING takes it wherever representable, NB_FLAG_NO_MASS_SCALING never, and
+    // by default choose_mass_scaling() below MEASURES it on the uploaded bodies (unsharded handles).
     s->mass_scaled = false;
+    s->mass_scaling_dev = -1.0f;
+    bool scalable = false;
     if (!s->uniform_mass && s->p.sum_order == NB_SUM_TILED && !needs_guard(s) && !s->fp64 && !s->dims3 &&
-        s->p.rsqrt_mode == NB_RSQRT_EXACT && (s->p.flags & NB_FLAG_MASS_SCALING)) {
+        s->p.rsqrt_mode == NB_RSQRT_EXACT && !(s->p.flags & NB_FLAG_NO_MASS_SCALING)) {
         double mmin = HUGE_VAL, mmax = 0.0;
         bool finite = true;
         for (size_t i = 0; i < s->n; ++i) {
@@ -617,8 +680,10 @@ static int do_upload(nb_sim *s, const nb_body *in)
             if (m > mmax) mmax = m;
         }
         const double eps = (double)s->p.eps;
-        s->mass_scaled = finite && mmin >= 1e-30 && std::pow(mmax, 1.5) / (eps * eps * eps) <= 1e36;
+        scalable = finite && mmin >= 1e-30 && std::pow(mmax, 1.5) / (eps * eps * eps) <= 1e36;
     }
+    const bool forced_scaling = scalable && (s->p.flags & NB_FLAG_MASS_SCALING);
+    const bool auto_scaling = scalable && !forced_scaling && s->i_count == s->n && !s->sym_sharded && !s->sym_replicated;
     { const int rc = copy_h2d(s, s->aos_dev, in, s->n * sizeof(nb_body)); if (rc) return rc; }
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
@@ -639,13 +704,15 @@ static int do_upload(nb_sim *s, const nb_body *in)
                                                             (uint32_t)s->i_begin, (uint32_t)s->i_count);
     }
     HIPCHK(hipGetLastError());
-    if (s->mass_scaled) {
+    if (forced_scaling || auto_scaling) {
         if (!s->sigma) HIPCHK(hipMalloc((void **)&s->sigma, s->n * sizeof(float)));
         mass_sigma<<<g, BLOCK, 0, s->stream>>>((const float *)s->mass, s->sigma, n);
         HIPCHK(hipGetLastError());
     }
+    s->mass_scaled = forced_scaling;
     HIPCHK(hipStreamSynchronize(s->stream));  // `in` may be pageable and freed by the caller
     s->acc_valid = false;
+    if (auto_scaling) { const int rc = choose_mass_scaling(s); if (rc) return rc; }
     return NB_OK;
 }
 
@@ -671,7 +738,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_NO_MASS_SCALING | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
@@ -1841,12 +1908,12 @@ extern "C" int nb_describe(nb_sim *s, char *buf, size_t buflen)
     const bool seq = s->p.sum_order == NB_SUM_SEQUENTIAL;
     snprintf(buf, buflen,
              "n=%zu owned=[%zu,+%zu) %s%s rsqrt=%s sum=%s | force: block=%d waves/i-set=%d i/lane=%d i_tiles=%u j_slices(all)=%u grid=%u tile_j=%d | "
-             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d | symmetric=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
+             "two-phase P/slices local=%d/%u remote=%d/%u | uniform_mass=%d mass_scaled=%d mass_scaling_check=%.1e | symmetric=%d tile=%u chunk_pairs=%d items=%u chunks/item=%u late=%u slabs=%.1f+%.1f MiB | CUs=%d",
              s->n, s->i_begin, s->i_count, s->fp64 ? "fp64" : "fp32", s->dims3 ? " 3-D" : "",
              s->p.rsqrt_mode == NB_RSQRT_QUAKE ? "quake" : "exact", seq ? "sequential" : "tiled",
              BLOCK, (seq || s->fp64) ? 1 : F32_WS, seq ? 1 : (s->fp64 ? a.P : 2 * a.P), a.i_tiles, a.js,
              seq ? a.i_tiles : grid_blocks(a.i_tiles, a.js), TJ,
-             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled,
+             s->job_local.P, s->job_local.js, s->job_remote.P, s->job_remote.js, (int)s->uniform_mass, (int)s->mass_scaled, (double)s->mass_scaling_dev,
              (int)(s->sym || s->sym_sharded || s->sym_replicated), s->sym_sb,
              (int)(s->sym_pairs && !s->mass_scaled && (!s->dims3 || s->uniform_mass || s->p.sym_chunk_pairs > 0)), s->sym_items, s->sym_L, s->sym_items_late,
              (double)s->sym_info.slab_s_bytes / 1048576.0, (double)s->sym_info.slab_r_bytes / 1048576.0, s->cus);

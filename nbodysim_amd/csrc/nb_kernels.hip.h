@@ -836,6 +836,29 @@ void mass_sigma(const float *__restrict__ mass, float *__restrict__ sigma, uint3
     if (i < n) sigma[i] = 1.0f / sqrtf(mass[i]);
 }
 
+// out[0] = max over particles and components of |a - b|, out[1] = max |b| (bit patterns of non-negative floats order like the
+// floats, so an unsigned atomic max does; a NaN difference — bit pattern above every finite float's — wins the max and the host
+// reads it as "not comparable").  The upload-time check of the mass-scaled body (nb_capi.hip: choose_mass_scaling).
+__global__ __launch_bounds__(BLOCK)
+void max_deviation_f32(const float2 *__restrict__ a, const float2 *__restrict__ b, uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    float d = 0.f, m = 0.f;
+    if (i < n) {
+        const float2 p = a[i], q = b[i];
+        const float dx = fabsf(p.x - q.x), dy = fabsf(p.y - q.y);
+        d = (dx > dy || dx != dx) ? dx : dy;              // a NaN stays
+        m = fmaxf(fabsf(q.x), fabsf(q.y));
+    }
+    uint32_t du = __float_as_uint(d), mu = __float_as_uint(m);
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t d2 = (uint32_t)__shfl_xor((int)du, off), m2 = (uint32_t)__shfl_xor((int)mu, off);
+        du = du > d2 ? du : d2;
+        mu = mu > m2 ? mu : m2;
+    }
+    if ((threadIdx.x & 63u) == 0u) { atomicMax(&out[0], du); atomicMax(&out[1], mu); }
+}
+
 // acc_sum[k] = sum of particle k's stationary rows (its tile's items held here, in item order;
 //              none if row_lo[g] == row_hi[g])
 //            + sum over the coverage list of its tile (the travelling segments held here that meet the

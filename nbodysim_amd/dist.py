@@ -458,19 +458,25 @@ class DistributedSimulation:
         self.sim = None
         self._broken = None
         try:
-            # full-n position replicas owned by torch so the collective can write them
-            self.pos = [torch.zeros((self.plan.padded_n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
-            # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
-            self.acc_full = self.acc_owned = None
-            acc_ptrs = None
-            replicated = protocol == "allreduce" and world > 1
-            if world > 1 and protocol != "allgather":
-                self.acc_full = torch.zeros((self.plan.n, self._width), dtype=self._dtype, device=self.device)
-                if replicated:
-                    acc_ptrs = (self.acc_full.data_ptr(), self.acc_full.data_ptr())
-                else:
-                    self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
-                    acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
+            # Full-n position replicas owned by torch so the collective can write them.  Allocated and zero-filled ON THE HANDLE'S
+            # STREAM: the library uploads the bodies into them on that stream, and torch's own (default) stream is not ordered
+            # against a non-blocking one — a zero-fill still queued there could land AFTER the upload and wipe the positions
+            # (found by the start-up validation in round 5: with four ranks time-sharing one GPU every few creations lost its
+            # positions that way).
+            with torch.cuda.stream(self.stream):
+                self.pos = [torch.zeros((self.plan.padded_n, self._width), dtype=self._dtype, device=self.device) for _ in range(2)]
+                # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
+                self.acc_full = self.acc_owned = None
+                acc_ptrs = None
+                replicated = protocol == "allreduce" and world > 1
+                if world > 1 and protocol != "allgather":
+                    self.acc_full = torch.zeros((self.plan.n, self._width), dtype=self._dtype, device=self.device)
+                    if replicated:
+                        acc_ptrs = (self.acc_full.data_ptr(), self.acc_full.data_ptr())
+                    else:
+                        self.acc_owned = torch.zeros((self.plan.i_count, self._width), dtype=self._dtype, device=self.device)
+                        acc_ptrs = (self.acc_full.data_ptr(), self.acc_owned.data_ptr())
+            self.stream.synchronize()
             kw = dict(self._args)
             kw.update(extra or {})
             if protocol == "allgather":
@@ -660,6 +666,10 @@ class DistributedSimulation:
                 if np.isfinite(per_step):
                     states[name] = got[0]
             validation[name] = v
+            if not np.isfinite(per_step) and self.plan.rank == 0:
+                sys.stderr.write(f"[tune] rank 0: {name} DISQUALIFIED: " + ", ".join(f"{a}={b}" for a, b in v.items() if a in
+                                 ("max_rel_pos", "max_rel_vel", "worst_particle", "worst_rank", "error", "vs_torch_loop", "replicas")) + "\n")
+                sys.stderr.flush()
             self.close()
             return per_step
 

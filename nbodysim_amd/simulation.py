@@ -62,7 +62,7 @@ class Simulation:
         shard_allreduce: bool = False,
         first_frame: int = 0,
         shard_single: bool = False,
-        mass_scaling: bool = False,
+        mass_scaling: Optional[bool] = None,
         sym_chunk_pairs: int = 0,
         sym_tile: int = 0,
         pos_rows: int = 0,
@@ -70,7 +70,9 @@ class Simulation:
         library=None,
     ):
         """The last arguments (from ``uniform_mass`` on) are ``nb_params.flags`` and the launch-geometry tuning fields
-        (0 / True = the library's automatic choice); the library reads no environment variables.  ``library``: another
+        (0 / True = the library's automatic choice); the library reads no environment variables.  ``mass_scaling``: None =
+        the library measures at upload whether folding the masses into the pair geometry is harmless for these bodies
+        (include/nbody.h, NB_FLAG_MASS_SCALING), True = fold wherever representable, False = never.  ``library``: another
         build of the library bound with ``_lib.bind`` (the tests' -DNB_TEST_HOOKS build); default the product."""
         lib = library if library is not None else L.load()
         if bodies.dtype not in (L.BODY_DTYPE, L.BODY3_DTYPE):
@@ -98,7 +100,8 @@ class Simulation:
         p.dims = dims
         p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
                    | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL) | (L.NB_FLAG_SHARD_ALLREDUCE if shard_allreduce else 0)
-                   | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0) | (L.NB_FLAG_MASS_SCALING if mass_scaling else 0)
+                   | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0)
+                   | (0 if mass_scaling is None else L.NB_FLAG_MASS_SCALING if mass_scaling else L.NB_FLAG_NO_MASS_SCALING)
                    | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:

@@ -65,6 +65,10 @@ def test_bench_line_contract():
     sc = rf["general_mass_scaled"]
     assert sc["mass_scaled"] is True and g["mass_scaled"] is False and sc["avg_launch_ms"] > 0
     assert sc["kernel_instantiation"] == "nbk::force_sym_f32<0, 2, false, true>"
+    # the default with individual masses: measured at upload; the equal light masses of this workload pass (~1e-7 of the force scale)
+    au = rf["general_mass_default"]
+    assert au["mass_scaled"] is True and 0 <= au["mass_scaling_check"] < 2e-6 and au["kernel_instantiation"] == sc["kernel_instantiation"]
+    assert g["mass_scaling_check"] is None and abs(rf["frac_individual_masses_default"] - au["frac"]) < 1e-12
     if d["device_state"]:                       # hwmon files readable on this box
         assert {"at_start", "at_end", "sclk_mhz_mean", "power_w_mean"} <= set(d["device_state"])
 
