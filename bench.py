@@ -314,6 +314,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s settled-rate measurement after the timed region")
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
+    ap.add_argument("--mass-scaling", default="auto", choices=["auto", "on", "off"],
+                    help="with --general-mass: fold the masses into the pair geometry — auto (the library measures at upload whether that is "
+                         "harmless for these bodies), on (NB_FLAG_MASS_SCALING), off (NB_FLAG_NO_MASS_SCALING: the 12 + 2 body)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
     ap.add_argument("--chunks-per-item", type=int, default=0, help="symmetric kernel: force nb_params.sym_chunks_per_item (tuning sweeps)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
@@ -740,6 +743,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
 
     ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)   # every rank generates the same deterministic ICs
+    scaling = {"auto": None, "on": True, "off": False}[args.mass_scaling]
 
     if world > 1:
         import datetime
@@ -771,11 +775,12 @@ def main() -> None:
             return DistributedSimulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device_index=local_rank,
                                          protocol=protocol, tune_dt=DT, driver=driver if args.backend == "nccl" else "torch",
                                          deadline_s=args.candidate_deadline, verify=not args.no_parity_check,
-                                         uniform_mass=not args.general_mass, dims=args.dims, sym_chunks_per_item=args.chunks_per_item)
+                                         uniform_mass=not args.general_mass, dims=args.dims, sym_chunks_per_item=args.chunks_per_item,
+                                         mass_scaling=scaling)
 
         def make_reference():
             return nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
-                                 uniform_mass=not args.general_mass)
+                                 uniform_mass=not args.general_mass, mass_scaling=scaling)
 
         status = run_sharded(args, ic, n, world, rank, make_sim, make_reference, torch.cuda.synchronize, dist.barrier)
         dist.destroy_process_group()
@@ -785,7 +790,8 @@ def main() -> None:
 
     # ---- one GPU ------------------------------------------------------------------------------------------------------
     sim = nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
-                        symmetry=not args.no_symmetry, uniform_mass=not args.general_mass, sym_chunks_per_item=args.chunks_per_item)
+                        symmetry=not args.no_symmetry, uniform_mass=not args.general_mass, sym_chunks_per_item=args.chunks_per_item,
+                        mass_scaling=scaling)
     m = timed_region(sim, args, 1, 0, lambda: None, torch.cuda.synchronize)
 
     # the settled rate, AFTER the timed region (never part of `value`)

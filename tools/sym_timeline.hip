@@ -8,7 +8,7 @@
 // workgroup end to the last one).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Inbodysim_amd/csrc -Iinclude -o build/sym_timeline tools/sym_timeline.hip nbodysim_amd/csrc/nb_plan.cpp
-//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [general=1] [pairs=0] [reps=20] [shift=0]
+//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [masses=1: 0 equal | 1 individual | 2 individual, mass-scaled body] [pairs=0] [reps=20] [shift=0]
 #include "nb_kernels.hip.h"
 
 #include <algorithm>
@@ -28,11 +28,11 @@ struct Stamp { unsigned long long t0, t1, c0, c1; unsigned hw_id, xcc_id; };
 
 template <int MM, bool PAIRS, bool WS>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
-void stamped(const float2 *pos, const float *mass, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st, uint32_t shift)
+void stamped(const float2 *pos, const float *mass, const float *sigma, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st, uint32_t shift)
 {
     if (blockIdx.x < shift) return;                     // `shift` idle workgroups in front: item i runs as workgroup i + shift (moves every item to another XCD)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
-    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS>(pos, mass, nullptr, items[blockIdx.x - shift], slab_s, slab_r, n, eps2, um);
+    force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS, true>(pos, mass, sigma, items[blockIdx.x - shift], slab_s, slab_r, n, eps2, um);   // write-through slab stores, like the product
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) {
         Stamp s;
@@ -48,7 +48,8 @@ int main(int argc, char **argv)
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 25000u;
     const uint32_t tile = argc > 2 ? (uint32_t)atoi(argv[2]) : 512u;
     const uint32_t L = argc > 3 ? (uint32_t)atoi(argv[3]) : 0u;
-    const bool general = argc > 4 ? atoi(argv[4]) != 0 : true;
+    const int mass_mode = argc > 4 ? atoi(argv[4]) : 1;          // 0 equal masses, 1 individual (12 + 2), 2 individual folded into the geometry (11 + 2)
+    const bool general = mass_mode != 0;
     const bool pairs = argc > 5 ? atoi(argv[5]) != 0 : false;
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
     const uint32_t shift = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;
@@ -61,18 +62,23 @@ int main(int argc, char **argv)
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<float2> hp(n); std::vector<float> hm(n);
     for (uint32_t i = 0; i < n; ++i) { hp[i] = make_float2(U(rng), U(rng)); hm[i] = general ? 0.5f + 0.5f * std::fabs(U(rng)) : 1.0f / n; }
-    float2 *pos, *ss, *sr; float *mass; SymItem *items; Stamp *st;
+    float2 *pos, *ss, *sr; float *mass, *sigma; SymItem *items; Stamp *st;
     const size_t rows = pl.rowbase[pl.tiles];
     CK(hipMalloc(&pos, n * sizeof(float2))); CK(hipMalloc(&mass, n * sizeof(float)));
     CK(hipMalloc(&ss, rows * tile * sizeof(float2))); CK(hipMalloc(&sr, (pl.slab_r_elems + 2) * sizeof(float2)));
     CK(hipMalloc(&items, pl.items.size() * sizeof(SymItem))); CK(hipMalloc(&st, pl.items.size() * sizeof(Stamp)));
     CK(hipMemcpy(pos, hp.data(), n * sizeof(float2), hipMemcpyHostToDevice));
     CK(hipMemcpy(mass, hm.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> hsig(n);
+    for (uint32_t i = 0; i < n; ++i) hsig[i] = 1.0f / std::sqrt(hm[i]);
+    CK(hipMalloc(&sigma, n * sizeof(float)));
+    CK(hipMemcpy(sigma, hsig.data(), n * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(items, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     const uint32_t grid = (uint32_t)pl.items.size();
     const float eps2 = 1e-4f, um = 1.0f / n;
     auto launch = [&]() {
-#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid + shift, BLOCK>>>(pos, mass, items, ss, sr, n, eps2, um, st, shift)
+#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid + shift, BLOCK>>>(pos, mass, sigma, items, ss, sr, n, eps2, um, st, shift)
+        if (mass_mode == 2) { if (tile == SYM_SB_WS) GO(MM_SCALED, false, true); else GO(MM_SCALED, false, false); return; }
         if (tile == SYM_SB_WS) { if (general) { if (pairs) GO(MM_GENERAL, true, true); else GO(MM_GENERAL, false, true); }
                                  else         { if (pairs) GO(MM_UNIFORM, true, true); else GO(MM_UNIFORM, false, true); } }
         else                   { if (general) { if (pairs) GO(MM_GENERAL, true, false); else GO(MM_GENERAL, false, false); }
@@ -96,7 +102,7 @@ int main(int argc, char **argv)
 
     // VALU cycles of the plan: a symmetric body (2 stationary x 1 travelling, both directions) = 10 packed (12 with masses) x 4 + 2 x 8
     // cycles; a diagonal one 8 (9) x 4 + 16; a wave runs 4 bodies per rotation step, 64 steps per chunk
-    const double cyc_sym = (general ? 12 : 10) * 4 + 16, cyc_diag = (general ? 9 : 8) * 4 + 16;
+    const double cyc_sym = (mass_mode == 2 ? 11 : general ? 12 : 10) * 4 + 16, cyc_diag = (mass_mode == 2 ? 8 : general ? 9 : 8) * 4 + 16;
     double work = 0;                                        // SIMD cycles of the whole launch
     std::vector<double> item_cyc(grid);
     for (uint32_t i = 0; i < grid; ++i) {
@@ -124,7 +130,7 @@ int main(int argc, char **argv)
     const double ideal_us = work / simds / (mhz > 0 ? mhz : 2400.0);
     double wmax = 0, wmin = 1e300; for (auto &kv : cu_work) { wmax = std::max(wmax, kv.second); wmin = std::min(wmin, kv.second); }
     int imax = 0, imin = 1 << 30; for (auto &kv : cu_items) { imax = std::max(imax, kv.second); imin = std::min(imin, kv.second); }
-    printf("n=%u tile=%u L=%u general=%d pairs=%d | items=%u rows=%zu | CUs=%d seen=%zu\n", n, tile, pl.L, (int)general, (int)pairs, grid, rows, cus, cu_work.size());
+    printf("n=%u tile=%u L=%u masses=%d pairs=%d | items=%u rows=%zu | CUs=%d seen=%zu\n", n, tile, pl.L, mass_mode, (int)pairs, grid, rows, cus, cu_work.size());
     printf("  launch wall (events): min %.1f median %.1f us | back-to-back %.1f us per launch\n", wall.front(), wall[wall.size() / 2], ms200 * 1e3 / 200);
     printf("  shader clock during the workgroups: %.0f MHz | VALU work of the plan at that clock on %d SIMDs: %.1f us (%.1f at 2400 MHz)\n",
            mhz, (int)simds, ideal_us, work / simds / 2400.0);
