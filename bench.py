@@ -418,6 +418,27 @@ def timed_region(sim, args, world, rank, barrier, device_sync, reference=None, p
             "phases_max": phases_max, "energy": (k0, u0, k1, u1), "parity": parity}
 
 
+def driver_reason(sim):
+    """Which host runs the step loop of a sharded run, and why (from the start-up timing's record)."""
+    t = getattr(sim, "tuning", None)
+    drv = getattr(sim, "driver", None)
+    if not t:
+        return f"{drv}: named on the command line (no start-up timing)" if drv else None
+    ms, val, chosen = t.get("ms_per_step", {}), t.get("validation", {}), t.get("chosen", "")
+    proto = chosen[2:] if chosen.startswith("c:") else chosen
+    c_ms, t_ms = ms.get("c:" + proto), ms.get(proto)
+    fmt = lambda v: "unavailable" if v is None else f"{v:.3f} ms/step"
+    if not any(k.startswith("c:") for k in ms):
+        return f"torch: the library's C loop was not a candidate ({'no RCCL process group (gloo rehearsal)' if drv == 'torch' else 'driver forced'})"
+    vs = (val.get("c:" + proto) or {}).get("vs_torch_loop")
+    why = f"C loop {fmt(c_ms)} vs torch-driven {fmt(t_ms)} in the start-up timing of the '{proto}' protocol"
+    if vs:
+        why += f"; C trial against the torch trial: {vs}"
+    if t.get("failed"):
+        why += f"; skipped by agreement: {sorted(t['failed'])}"
+    return f"{drv}: {why}"
+
+
 def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     """The ONE JSON line (rank 0) from a timed region's measurement `m` (timed_region) of `sim`."""
     inner = sim.sim if world > 1 else sim
@@ -510,6 +531,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             "protocol": getattr(sim, "protocol", None) if world > 1 else None,
             "protocol_tuning": getattr(sim, "tuning", None) if world > 1 else None,
             "driver": getattr(sim, "driver", None) if world > 1 else None,
+            "driver_choice": driver_reason(sim) if world > 1 else None,
             "uniform_mass_specialisation": um,
             "launch": inner.describe(),
         },

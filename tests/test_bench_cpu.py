@@ -67,3 +67,22 @@ def test_pmc_figures_are_reported_only_for_the_kernel_that_ran():
     assert b.pmc_lookup({}, k, 262144, 8187) == (None, "none") and b.pmc_lookup(book, None, 262144, 8187)[0] is None
     # the single-record file of rounds 1-3 (no entries list) is never matched: it names no full instantiation and no commit
     assert b.pmc_lookup({"kernel": "nbk::force_sym_f32<0, 0, true>", "n": 262144}, k, 262144, 8187) == (None, "none")
+
+
+def test_the_line_says_which_host_loop_won_and_why():
+    """config.driver_choice: derived from the start-up timing's record."""
+    b = load_bench()
+
+    class Sim:
+        pass
+    s = Sim()
+    s.driver = "c"
+    s.tuning = {"ms_per_step": {"allgather": 1.6, "symmetric": 1.05, "c:symmetric": 0.98, "c:allgather": None},
+                "validation": {"c:symmetric": {"vs_torch_loop": "bit-identical"}}, "chosen": "c:symmetric", "failed": {"c:allreduce": "x"}}
+    why = b.driver_reason(s)
+    assert why.startswith("c: C loop 0.980 ms/step vs torch-driven 1.050 ms/step") and "bit-identical" in why and "c:allreduce" in why
+    s.driver, s.tuning = "torch", {"ms_per_step": {"allgather": 1.6, "symmetric": 1.05}, "validation": {}, "chosen": "symmetric", "failed": {}}
+    assert b.driver_reason(s).startswith("torch: the library's C loop was not a candidate")
+    s.tuning = None
+    assert "named on the command line" in b.driver_reason(s)
+    assert b.parse_args([]).driver == "tune" and b.parse_args([]).protocol == "tune"        # the defaults of a node run

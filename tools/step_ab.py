@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""One launch per step (sym_step_f32: the gather + kick + drift workgroups ride in the drain of the force launch) against
-two launches per step (force_sym_f32 + sym_gather), same handle parameters, interleaved rounds on one box; also checks
-that the two forms leave bit-identical bodies.
+"""A/B of ONE switch of `nbodysim_amd.Simulation` on one box: the same workloads with the switch off and on, in interleaved
+rounds (the clock a part holds drifts within a call), with a bit comparison of the final bodies where the switch promises
+the same bits.
 
-    python tools/step_ab.py [--cases ref25000,p16384,...] [--general] [--rounds 2] [--extra sym_tile=512,...]
+    python tools/step_ab.py --what dynamic_items                     # dynamic against static work items (same bits)
+    python tools/step_ab.py --what mass_scaling --general            # 12 + 2 body against 11 + 2 (different rounding: not the same bits)
+    python tools/step_ab.py [--cases ref25000,p16384,...] [--rounds 2] [--extra sym_tile=512,...]
 """
 from __future__ import annotations
 
@@ -47,6 +49,14 @@ def same(a, b):
     return all(np.array_equal(np.ascontiguousarray(a[f]).view(np.uint32), np.ascontiguousarray(b[f]).view(np.uint32)) for f in ("pos", "vel", "acc"))
 
 
+#: switch -> (label A, keywords A, label B, keywords B, do the two sides promise the same bits?)
+SWITCHES = {
+    "dynamic_items": ("static items", dict(static_items=True), "dynamic items", dict(static_items=False), True),
+    "mass_scaling": ("12 + 2 body", dict(mass_scaling=False), "11 + 2 body (masses folded)", dict(mass_scaling=True), False),
+    "guided_tail": ("uniform items", dict(guided_tail=False), "guided tail", dict(guided_tail=True), True),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="p9216,p16384,ref25000,p32768,p49152,p65536,p131072,p262144")
@@ -54,7 +64,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--general", action="store_true")
-    ap.add_argument("--what", default="one_launch", choices=("one_launch", "dynamic_items"), help="the switch under test: one launch per step against two (default), or dynamic against static work items")
+    ap.add_argument("--what", default="dynamic_items", choices=sorted(SWITCHES), help="the switch under test")
     ap.add_argument("--extra", default="", help="comma-separated key=int tuning fields passed to both sides")
     args = ap.parse_args()
     extra = {k: int(v) for k, v in (kv.split("=") for kv in args.extra.split(",") if kv)}
@@ -66,20 +76,12 @@ def main():
                 kw["uniform_mass"] = False
             steps = max(20, min(args.steps, int(args.steps * (65536.0 / n) ** 2)))
             frac = lambda ms: 14.0 * n * n / (ms * 1e-3) / PEAK
-            if args.what == "dynamic_items":
-                two, info, d2, e2 = run(ic, kw, dt, steps, args.reps, static_items=True, **extra)
-                one, _, d1, e1 = run(ic, kw, dt, steps, args.reps, static_items=False, **extra)
-                print(f"round {rnd + 1} {name:10s} n={n:7d} tile={info['tile_particles']:4d} L={info['chunks_per_item']:3d} items={info['items']:5d} steps={steps:3d} | "
-                      f"static items {two*1e3:9.1f} us/step frac {frac(two):.3f} | dynamic items {one*1e3:9.1f} us/step frac {frac(one):.3f} "
-                      f"({(one/two-1)*100:+.1f} %) | bit-identical {same(e1, e2)}", flush=True)
-                continue
-            two, info, d2, e2 = run(ic, kw, dt, steps, args.reps, one_launch=False, **extra)
-            one, _, d1, e1 = run(ic, kw, dt, steps, args.reps, one_launch=True, **extra)
-            assert "one_launch=0" in d2 and "one_launch=1" in d1, (d1, d2)
+            label_a, kw_a, label_b, kw_b, same_bits = SWITCHES[args.what]
+            ta, info, _, ea = run(ic, kw, dt, steps, args.reps, **kw_a, **extra)
+            tb, _, desc, eb = run(ic, kw, dt, steps, args.reps, **kw_b, **extra)
             print(f"round {rnd + 1} {name:10s} n={n:7d} tile={info['tile_particles']:4d} L={info['chunks_per_item']:3d} items={info['items']:5d} steps={steps:3d} | "
-                  f"two launches {two*1e3:9.1f} us/step frac {frac(two):.3f} | one launch {one*1e3:9.1f} us/step frac {frac(one):.3f} "
-                  f"({(one/two-1)*100:+.1f} %) | bit-identical {same(e1, e2)}", flush=True)
-
+                  f"{label_a} {ta*1e3:9.1f} us/step frac {frac(ta):.3f} | {label_b} {tb*1e3:9.1f} us/step frac {frac(tb):.3f} "
+                  f"({(tb/ta-1)*100:+.1f} %) | " + (f"bit-identical {same(ea, eb)}" if same_bits else "(different rounding by design)"), flush=True)
 
 if __name__ == "__main__":
     main()
