@@ -8,7 +8,9 @@
 // workgroup end to the last one).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Inbodysim_amd/csrc -Iinclude -o build/sym_timeline tools/sym_timeline.hip nbodysim_amd/csrc/nb_plan.cpp
-//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [masses=1: 0 equal | 1 individual | 2 individual, mass-scaled body] [pairs=0] [reps=20] [shift=0]
+//   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [masses=1: 0 equal | 1 individual | 2 individual, mass-scaled body] [pairs=0] [reps=20] [shift=0] [stagger=0]
+//   stagger = k > 0 (experiment): among the first `stagger` items of the list every other adjacent pair of symmetric items of the same
+//   tile is MERGED into one item of twice the chunks, so that the workgroups that start together on a CU no longer end together
 #include "nb_kernels.hip.h"
 
 #include <algorithm>
@@ -53,11 +55,28 @@ int main(int argc, char **argv)
     const bool pairs = argc > 5 ? atoi(argv[5]) != 0 : false;
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
     const uint32_t shift = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;
+    const int stagger = argc > 8 ? atoi(argv[8]) : 0;            // > 0: desynchronise the workgroups that share a CU (see below)
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
 
     SymTuning t; t.sb = tile; t.forced_L = L; t.even_chunks = pairs;
     SymPlan pl; build_sym_plan(n, (uint32_t)cus, 0, 1, t, pl);
+    if (stagger > 0) {
+        std::vector<SymItem> out;
+        size_t merged = 0;
+        for (size_t i = 0; i < pl.items.size(); ++i) {
+            const SymItem &a = pl.items[i];
+            if ((int)out.size() < stagger && i + 1 < pl.items.size() && ((out.size() / 2) & 1u) == 0u) {
+                const SymItem &b = pl.items[i + 1];
+                if (!a.diag && !b.diag && a.tile == b.tile && a.c0 + a.cnt == b.c0 && a.r_base == b.r_base) {
+                    SymItem m = a; m.cnt = a.cnt + b.cnt; out.push_back(m); ++i; ++merged; continue;
+                }
+            }
+            out.push_back(a);
+        }
+        fprintf(stderr, "stagger: %zu pairs merged, %zu -> %zu items\n", merged, pl.items.size(), out.size());
+        pl.items.swap(out);
+    }
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<float2> hp(n); std::vector<float> hm(n);
@@ -182,5 +201,34 @@ int main(int argc, char **argv)
     printf("  workgroup ends: 10%% %.1f median %.1f 90%% %.1f last %.1f us\n", ends[(size_t)(0.1 * grid)], ends[grid / 2], ends[(size_t)(0.9 * grid)], ends.back());
     printf("  per CU: items min %d max %d | VALU work max / mean = %.3f, min / mean = %.3f -> busiest CU alone needs %.1f us at that clock\n",
            imin, imax, wmax / (work / cu_work.size()), wmin / (work / cu_work.size()), wmax / 4.0 / (mhz > 0 ? mhz : 2400.0));
+    {   // residency: how long does a CU hold 4 / 3 / 2 / 1 / 0 workgroups between the launch's first start and last end?  (mean over CUs)
+        std::map<unsigned, std::vector<std::pair<double, int>>> ev;
+        for (uint32_t i = 0; i < grid; ++i) {
+            const Stamp &q = hs[i];
+            const unsigned cu = (q.xcc_id & 0xf) << 16 | ((q.hw_id >> 13) & 0x7) << 8 | ((q.hw_id >> 8) & 0xf);
+            ev[cu].push_back({(q.t0 - tmin) * 0.01, +1}); ev[cu].push_back({(q.t1 - tmin) * 0.01, -1});
+        }
+        double held[6] = {0, 0, 0, 0, 0, 0};
+        const double end = (tmax - tmin) * 0.01;
+        unsigned busiest = 0; double bw = -1; for (auto &kv : cu_work) if (kv.second > bw) { bw = kv.second; busiest = kv.first; }
+        for (auto &kv : ev) {
+            auto &v = kv.second; std::sort(v.begin(), v.end());
+            double t = 0; int k = 0;
+            for (auto &e : v) { held[k > 5 ? 5 : k] += e.first - t; t = e.first; k += e.second; }
+            held[0] += end - t;
+        }
+        printf("  residency, mean over CUs (us with k workgroups resident):");
+        for (int k = 0; k <= 5; ++k) printf("  %d: %.1f", k, held[k] / ev.size());
+        printf("\n  busiest CU, its workgroups (start-end us):");
+        std::vector<std::pair<double, double>> w;
+        for (uint32_t i = 0; i < grid; ++i) {
+            const Stamp &q = hs[i];
+            const unsigned cu = (q.xcc_id & 0xf) << 16 | ((q.hw_id >> 13) & 0x7) << 8 | ((q.hw_id >> 8) & 0xf);
+            if (cu == busiest) w.push_back({(q.t0 - tmin) * 0.01, (q.t1 - tmin) * 0.01});
+        }
+        std::sort(w.begin(), w.end());
+        for (auto &x : w) printf(" %.1f-%.1f", x.first, x.second);
+        printf("\n");
+    }
     return 0;
 }
