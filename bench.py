@@ -155,10 +155,10 @@ def sustained_steps(ms_per_step_hint, min_seconds=2.0):
 
 def reduce_max_over_ranks(value, world):
     """MAX of a host float over the ranks of the default process group (the identity for one rank)."""
-    if world <= 1:
+    import torch.distributed as dist
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
         return float(value)
     import torch
-    import torch.distributed as dist
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -322,6 +322,10 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="multi-GPU: skip the self-check of the sharded trajectory against one unsharded handle on rank 0")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="ONE GPU, one rank: run the whole multi-rank flow anyway — process group (RCCL, one rank), sharded handles "
+                         "(NB_FLAG_SHARD_SINGLE), safe-first measurement, start-up timing of every protocol under both step loops, "
+                         "self-checks, the N > 1 line.  A rehearsal of the code a node run executes, not a measurement")
     ap.add_argument("--no-safe-first", action="store_true",
                     help="multi-GPU: do not measure the plain all-gather / torch-driven configuration before anything else is tried")
     return ap.parse_args(argv)
@@ -360,26 +364,27 @@ def timed_region(sim, args, world, rank, barrier, device_sync, reference=None, p
     after the timed steps (reported; the caller decides).  Returns the measurement as a dictionary."""
     from nbodysim_amd.dist import ParityError, compare_with_unsharded
 
-    inner = sim.sim if world > 1 else sim
+    sharded = world > 1 or hasattr(sim, "plan")        # a DistributedSimulation — also the single-rank rehearsal of one
+    inner = sim.sim if sharded else sim
     phase = phase if phase is not None else {}
     parity = None
     k0, u0 = sim.energy()
     phase["now"] = f"{label}warm-up"
     sim.advance(args.warmup, DT)
     sim.wait()
-    if world > 1 and check:
+    if sharded and check:
         phase["now"] = f"{label}self-check after the warm-up"
         parity = compare_with_unsharded(sim.owned_rows(), sim.plan, (lambda: reference.rows(args.warmup)) if reference else None, args.warmup)
         if not parity["ok"]:
             raise ParityError(f"{label}{sim.protocol} protocol, {sim.driver} loop, after the warm-up", parity)
     if not args.no_kernel_events:
         inner.profile(True)
-        if world > 1:
+        if sharded:
             sim.profile_phases(True)
     phase["now"] = f"{label}timed region"
     barrier()
     device_sync()
-    sampler = DeviceSampler(period_s=0.02 if world == 1 else 0.1) if rank == 0 else None   # rare on the Python-driven sharded loop
+    sampler = DeviceSampler(period_s=0.02 if not sharded else 0.1) if rank == 0 else None   # rare on the Python-driven sharded loop
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
@@ -393,12 +398,12 @@ def timed_region(sim, args, world, rank, barrier, device_sync, reference=None, p
     if not args.no_kernel_events:
         force_ms, launches = inner.profile_read()
         inner.profile(False)
-    phases = sim.phase_report() if (world > 1 and not args.no_kernel_events) else None
-    if world > 1 and not args.no_kernel_events:
+    phases = sim.phase_report() if (sharded and not args.no_kernel_events) else None
+    if sharded and not args.no_kernel_events:
         sim.profile_phases(False)
     k1, u1 = sim.energy()
     phases_max = None
-    if world > 1:
+    if sharded:
         import torch
         import torch.distributed as dist
         from nbodysim_amd.dist import _comm_device
@@ -441,7 +446,8 @@ def driver_reason(sim):
 
 def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     """The ONE JSON line (rank 0) from a timed region's measurement `m` (timed_region) of `sim`."""
-    inner = sim.sim if world > 1 else sim
+    sharded = world > 1 or hasattr(sim, "plan")
+    inner = sim.sim if sharded else sim
     secondary = secondary or {}
     general, scaled, lds_tiled, auto = secondary.get("general"), secondary.get("scaled"), secondary.get("lds_tiled"), secondary.get("auto")
     elapsed, force_ms, launches = m["elapsed"], m["force_ms"], m["launches"]
@@ -455,9 +461,9 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     um = "uniform_mass=1" in inner.describe()
     kernel = ("force_sym" if symmetric else "force_tiled") + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64")
     # force launches per step on this rank: 1 (single GPU) or up to 3 (local + cross + late / local + remote ranges)
-    owned = sim.plan.i_count if world > 1 else n                        # rank 0's block (ragged splits: ceil(n / world))
+    owned = sim.plan.i_count if sharded else n                        # rank 0's block (ragged splits: ceil(n / world))
     pairs_this_rank = float(owned) * float(n) * args.steps             # its share of the ordered pairs, whatever the protocol
-    if launches and force_ms > 0 and world == 1:
+    if launches and force_ms > 0 and not sharded:
         kern_s = force_ms * 1e-3
         avg_launch_ms = force_ms / launches
     else:
@@ -469,12 +475,12 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     # flops the kernel really issues per launch (whole system on one GPU): symmetric items evaluate each unordered
     # pair once for both particles, the diagonal items and the one-sided kernel every ordered pair
     ex = EXECUTED[(args.precision, args.dims)]
-    if symmetric and world == 1:
+    if symmetric and not sharded:
         tile = float(info.get("tile_particles") or 2048)        # 2048 (classic) or 512 (wave-split kernels) stationary particles per item
         diag_units = info["tiles"] * tile / 64.0                 # every tile meets its own chunks one-sidedly
         sym_units = info["units_local"] + info["units_cross"] + info["units_late"] - diag_units
         exec_flop = (sym_units * ex["sym"][0 if um else 1] + diag_units * ex["one"][0 if um else 1]) * tile * 64.0
-    elif world == 1:
+    elif not sharded:
         exec_flop = ex["one"][0 if um else 1] * pairs_per_step
     else:
         exec_flop = None
@@ -482,21 +488,21 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     # HBM bytes of one launch from the work plan: every item writes its stationary row and its travelling
     # partials once (plain stores, no re-reads); the positions (and masses) are read from HBM once, later reads hit L2
     esz = (8 if args.precision == "fp32" else 16) * (2 if args.dims == 3 else 1)
-    traffic = float(info["slab_s_bytes"] + info["slab_r_bytes"] + n * esz) if (symmetric and world == 1) else None
+    traffic = float(info["slab_s_bytes"] + info["slab_r_bytes"] + n * esz) if (symmetric and not sharded) else None
     book = {}
     tfile = ROOT / "profiles" / "hbm_traffic.json"   # PMC-derived (tools/gpu_round.sh pmc + tools/summarize_profile.py)
-    if tfile.exists() and world == 1:
+    if tfile.exists() and not sharded:
         try:
             book = json.loads(tfile.read_text())
         except Exception:
             book = {}
-    kernel_full = kernel_instantiation(inner.describe(), args.precision, args.dims, args.rsqrt) if world == 1 else None
+    kernel_full = kernel_instantiation(inner.describe(), args.precision, args.dims, args.rsqrt) if not sharded else None
     pmc, pmc_status = pmc_lookup(book, kernel_full, n, info["items"])
     pmc_ok = pmc is not None
     pmc = pmc or {}
     traffic_pmc = pmc.get("force_kernel_hbm_bytes_per_launch") if pmc_ok else None
     traffic_reported = traffic_pmc if traffic_pmc else traffic           # ONE figure: `traffic`, the bandwidth and the intensity below use it
-    if world == 1:
+    if not sharded:
         workload = (f"N={n} {args.precision} direct O(N^2), one MI355X, kernel {kernel}: "
                     + (f"symmetric pair items ({info['items']} workgroups x {info['chunks_per_item']} chunks of 64, stationary particles in "
                        f"registers, travelling chunk rotated through the lanes)" if symmetric else "one-sided, j-particles through LDS tiles of 256"))
@@ -526,12 +532,12 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
         "config": {
             "workload": workload,
             "n": n, "eps": EPS, "dt": DT, "rsqrt": args.rsqrt, "sum_order": "tiled", "dims": args.dims,
-            "parallelism": f"i-block x{world}" if world > 1 else "single GPU",
-            "backend": args.backend if world > 1 else None,
-            "protocol": getattr(sim, "protocol", None) if world > 1 else None,
-            "protocol_tuning": getattr(sim, "tuning", None) if world > 1 else None,
-            "driver": getattr(sim, "driver", None) if world > 1 else None,
-            "driver_choice": driver_reason(sim) if world > 1 else None,
+            "parallelism": f"i-block x{world}" if sharded else "single GPU",
+            "backend": args.backend if sharded else None,
+            "protocol": getattr(sim, "protocol", None) if sharded else None,
+            "protocol_tuning": getattr(sim, "tuning", None) if sharded else None,
+            "driver": getattr(sim, "driver", None) if sharded else None,
+            "driver_choice": driver_reason(sim) if sharded else None,
             "uniform_mass_specialisation": um,
             "launch": inner.describe(),
         },
@@ -546,8 +552,8 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             "mass_model": mass_note,
             # the two headline fractions side by side: the contract's synthetic data has equal masses, the
             # reference's own bodies (Simulation.hpp:565-577) do not
-            "frac_equal_masses": (achieved / peak) if (um and world == 1) else None,
-            "frac_individual_masses": ((achieved / peak) if (not um and world == 1) else (frac_of(general["avg_launch_ms"]) if general else None)),
+            "frac_equal_masses": (achieved / peak) if (um and not sharded) else None,
+            "frac_individual_masses": ((achieved / peak) if (not um and not sharded) else (frac_of(general["avg_launch_ms"]) if general else None)),
             "frac_individual_masses_default": (frac_of(auto["avg_launch_ms"]) if auto else None),
             "executed_tflops": executed,
             "executed_frac": executed / peak if executed else None,
@@ -602,7 +608,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
         "energy": {"e0": k0 + u0, "e1": k1 + u1, "rel_drift": (k1 + u1 - k0 - u0) / (k0 + u0),
                    "steps": args.warmup + args.steps},
     }
-    if world > 1:
+    if sharded:
         line["phases_ms"] = {"rank0": m["phases"], "max_over_ranks": m["phases_max"],
                              "note": "per step, on the compute stream (waits included): local pairs | wait for the all-gather | "
                                      "cross pairs + slab gather | reduce-scatter | kick+drift; the all-gather itself runs on RCCL's stream"}
@@ -767,7 +773,8 @@ def main() -> None:
     ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)   # every rank generates the same deterministic ICs
     scaling = {"auto": None, "on": True, "off": False}[args.mass_scaling]
 
-    if world > 1:
+    rehearsal = args.rehearse_sharded and world == 1
+    if world > 1 or rehearsal:
         import datetime
 
         import torch.distributed as dist
@@ -775,6 +782,13 @@ def main() -> None:
         from nbodysim_amd.dist import DistributedSimulation, Watchdog
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal and "MASTER_PORT" not in os.environ:        # plain `python bench.py --rehearse-sharded`: a process group of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # no wait without an end: the process group's own collective timeout (its watchdog aborts the process) and, around the
         # whole run, a wall-clock deadline that names the phase the rank was in (run_sharded)
         pg_timeout = datetime.timedelta(seconds=max(60.0, min(600.0, args.deadline or 600.0)))
@@ -798,7 +812,7 @@ def main() -> None:
                                          protocol=protocol, tune_dt=DT, driver=driver if args.backend == "nccl" else "torch",
                                          deadline_s=args.candidate_deadline, verify=not args.no_parity_check,
                                          uniform_mass=not args.general_mass, dims=args.dims, sym_chunks_per_item=args.chunks_per_item,
-                                         mass_scaling=scaling)
+                                         mass_scaling=scaling, rehearse_single_rank=rehearsal)
 
         def make_reference():
             return nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,

@@ -162,12 +162,13 @@ class ShardPlan:
         return slice(rank * self.stride, min((rank + 1) * self.stride, self.n))
 
 
-def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False):
+def exchange_positions(full, plan: ShardPlan, group=None, async_op: bool = False, even_alone: bool = False):
     """All-gather the owned block of ``full`` (an (n, 2) torch tensor, any device)
-    into every rank's ``full`` in place.  Returns the Work handle if async."""
+    into every rank's ``full`` in place.  Returns the Work handle if async.  ``even_alone``: issue the collective with one
+    rank too (the single-rank rehearsal of the sharded path: RCCL's one-rank all-gather)."""
     import torch.distributed as dist
 
-    if plan.world == 1:
+    if plan.world == 1 and not even_alone:
         return None
     if full.shape[0] != plan.padded_n:
         raise ValueError(f"the replica must hold padded_n = {plan.padded_n} rows (n = {plan.n}, {plan.world} ranks), not {full.shape[0]}")
@@ -314,9 +315,9 @@ def gather_rows(owned: np.ndarray, plan: ShardPlan, group=None) -> np.ndarray:
     owned = np.ascontiguousarray(owned, dtype=np.float64)
     if owned.ndim != 2 or owned.shape[0] != plan.i_count:
         raise ValueError(f"rank {plan.rank} owns {plan.i_count} rows, got an array of shape {owned.shape}")
-    if plan.world == 1:
+    if plan.world == 1 and not dist.is_initialized():
         return owned.copy()
-    dev = _comm_device(group)
+    dev = _comm_device(group)                     # one rank of an initialised group still goes through the collective (rehearsals)
     mine = torch.zeros((plan.stride, owned.shape[1]), dtype=torch.float64)
     mine[: plan.i_count] = torch.from_numpy(owned)
     mine = mine.to(dev)
@@ -352,7 +353,7 @@ def compare_with_unsharded(owned: np.ndarray, plan: ShardPlan, reference: Option
         except Exception as e:          # noqa: BLE001 - the other ranks wait in the broadcast below: always get there
             err = f"the unsharded reference failed on rank 0: {type(e).__name__}: {e}"
             res[4] = 1.0
-    if plan.world > 1:
+    if plan.world > 1 or dist.is_initialized():
         t = torch.from_numpy(res).to(_comm_device(group))
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         res = t.cpu().numpy()
@@ -390,6 +391,10 @@ class DistributedSimulation:
                             BITS as the torch-driven trial of the same protocol (all-gather protocol: required; the
                             reducing protocols: bit-identical or within 1e-6, RCCL being free to order a sum differently
                             in another communicator) — ``tuning["validation"]`` says which.
+    rehearse_single_rank  with ONE rank: run the sharded protocols anyway (NB_FLAG_SHARD_SINGLE: every pair is local, the
+               collectives are RCCL's one-rank forms), including the start-up timing — all of a node run's start-up code on a
+               one-GPU box: both step loops as candidates of every protocol, the validation against the unsharded handle, the
+               C-loop-against-torch-loop comparison (tests/test_dist_gpu.py).  Never faster than a plain handle.
     verify     (start-up timing only) every candidate's trial state is gathered and compared on rank 0 with ONE unsharded
                handle advanced the same steps; a candidate further than 1e-5 (north_star's tolerance) from it is
                disqualified like an unavailable one — a protocol that mis-orders an exchange on this node cannot win.
@@ -400,7 +405,7 @@ class DistributedSimulation:
     def __init__(self, bodies: np.ndarray, eps: float = 1.0, precision: str = "fp32", rsqrt: str = "exact",
                  order: str = "tiled", device_index: Optional[int] = None, group=None, j_slices: int = 0,
                  protocol: str = "auto", tune_steps: int = 12, tune_dt: float = 1e-3, driver: str = "torch",
-                 deadline_s: float = 120.0, verify: bool = True, **sim_kwargs):
+                 deadline_s: float = 120.0, verify: bool = True, rehearse_single_rank: bool = False, **sim_kwargs):
         import torch
         import torch.distributed as dist
 
@@ -414,6 +419,8 @@ class DistributedSimulation:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.plan = ShardPlan(int(bodies.shape[0]), world, rank)
+        self._single = bool(rehearse_single_rank) and world == 1 and dist.is_initialized()
+        self._multi = world > 1 or self._single            # the handle runs a sharded protocol
         if device_index is None:
             device_index = torch.cuda.current_device()
         self.device = torch.device("cuda", device_index)
@@ -439,7 +446,7 @@ class DistributedSimulation:
         self._broken: Optional[BaseException] = None   # first failure of a compute call of the torch-driven loop (see step())
 
         extra: dict = {}
-        if world > 1 and (protocol == "tune" or driver == "tune"):
+        if self._multi and (protocol == "tune" or driver == "tune"):
             protocol, extra, driver = self._tune(bodies, tune_steps, tune_dt, driver, None if protocol == "tune" else protocol)
         elif protocol == "tune":
             protocol = "auto"
@@ -468,8 +475,8 @@ class DistributedSimulation:
                 # buffers of the symmetric protocol (partial acceleration of all particles / summed owned block)
                 self.acc_full = self.acc_owned = None
                 acc_ptrs = None
-                replicated = protocol == "allreduce" and world > 1
-                if world > 1 and protocol != "allgather":
+                replicated = protocol == "allreduce" and self._multi
+                if self._multi and protocol != "allgather":
                     self.acc_full = torch.zeros((self.plan.n, self._width), dtype=self._dtype, device=self.device)
                     if replicated:
                         acc_ptrs = (self.acc_full.data_ptr(), self.acc_full.data_ptr())
@@ -485,13 +492,13 @@ class DistributedSimulation:
                 bodies, device=self._device_index,
                 i_begin=0 if replicated else self.plan.i_begin, i_count=self.plan.n if replicated else self.plan.i_count,
                 stream=self.stream.cuda_stream, pos_buffers=(self.pos[0].data_ptr(), self.pos[1].data_ptr()), pos_rows=self.plan.padded_n,
-                shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, shard_allreduce=replicated, **kw,
+                shard_rank=rank, shard_world=world, acc_buffers=acc_ptrs, shard_allreduce=replicated, shard_single=self._single, **kw,
             )
         except (L.NBodyError, RuntimeError, MemoryError) as e:   # keep going to the collective below
             err = e
         self.symmetric = err is None and self.sim.shard_protocol == L.NB_SHARD_SYMMETRIC
         self.replicated = err is None and self.sim.shard_protocol == L.NB_SHARD_ALLREDUCE
-        if world > 1:
+        if self._multi:
             info = self.sim.sym_info() if err is None else {}
             vec = [
                 0 if err is not None else 1,
@@ -513,7 +520,7 @@ class DistributedSimulation:
                                    + (f"; this rank: {err}" if err is not None else "")) from err
         elif err is not None:
             raise err
-        if world > 1 and ((protocol == "symmetric" and not self.symmetric) or (protocol == "allreduce" and not self.replicated)):
+        if self._multi and ((protocol == "symmetric" and not self.symmetric) or (protocol == "allreduce" and not self.replicated)):
             self.sim.close()
             raise RuntimeError(f"protocol='{protocol}' requested but the system is not eligible "
                                "(needs eps > 0, tiled sum, blocks of whole 2048-particle tiles, n/world >= 4096)")
@@ -774,7 +781,7 @@ class DistributedSimulation:
             self._compute(self.sim.step_finish)      # (all-gather protocol: remote j-blocks,) kick, drift -> NEXT becomes CURRENT
             self._mark(marks)
             self._cur ^= 1
-            self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True)
+            self._pending = exchange_positions(self.pos[self._cur], self.plan, self.group, async_op=True, even_alone=self._single)
         self._host_enqueue_s += time.perf_counter() - t_host
         self._host_steps += 1
         if marks is not None:

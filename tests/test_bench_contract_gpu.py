@@ -117,3 +117,25 @@ def test_bench_line_of_a_two_rank_rehearsal():
     assert ph["rank0"]["steps"] == 4 and ph["max_over_ranks"]["stream_total"] > 0
     assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert abs(d["energy"]["rel_drift"]) < 1e-3
+
+
+def test_bench_single_rank_rehearsal_of_the_node_flow_through_rccl():
+    """`bench.py --rehearse-sharded`: the WHOLE multi-rank flow with the one rank a one-GPU box allows, through RCCL itself (a
+    process group of one, NB_FLAG_SHARD_SINGLE handles): safe-first measurement, start-up timing of every protocol under BOTH
+    step loops (the library's C loop must reproduce the torch-driven trial bit for bit — with one rank every sum is a copy),
+    self-checks before and after the timed steps, and the N > 1 form of the line."""
+    d = run_bench("--rehearse-sharded", "--n", "32768", "--steps", "4", "--warmup", "1", "--no-sustained")
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["parallelism"] == "i-block x1" and "cpu_baseline" not in d
+    t = d["config"]["protocol_tuning"]
+    timed = {k for k, v in t["ms_per_step"].items() if v is not None}
+    assert {"allgather", "allreduce", "symmetric", "c:allgather", "c:allreduce", "c:symmetric"} <= timed and t["failed"] == {}
+    assert all(t["validation"][k]["ok"] for k in timed)
+    assert all(t["validation"][k]["vs_torch_loop"] == "bit-identical" for k in timed if k.startswith("c:"))
+    assert d["config"]["driver"] in ("c", "torch") and d["config"]["driver_choice"].startswith(d["config"]["driver"] + ":")
+    assert "C loop" in d["config"]["driver_choice"] and "torch-driven" in d["config"]["driver_choice"]
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["max_rel_pos"] < 1e-5 and pc["after_timed_region"]["ok"] is True and pc["after_timed_region"]["steps"] == 5
+    sf = d["config"]["safe_first"]
+    assert sf["protocol"] == "allgather" and sf["driver"] == "torch" and sf["parity_check"]["ok"] is True
+    assert d["fallback"] == {"used": False} and d["phases_ms"]["rank0"]["steps"] == 4
+    assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -319,3 +319,58 @@ def test_c_driver_of_the_sharded_simulation_one_rank(tmp_path):
     assert np.array_equal(got.view(np.uint32), pos.view(np.uint32))
     e = np.load(tmp_path / "energy.npy")
     assert abs(e[0] + e[1] - k0 - u0) < 1e-12 * abs(k0 + u0) and abs(e[2] + e[3] - k1 - u1) < 1e-12 * abs(k1 + u1)
+
+
+def _rehearsal_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import json
+
+    import torch
+    import torch.distributed as dist
+
+    import nbodysim_amd as nb
+    from nbodysim_amd.dist import DistributedSimulation, compare_with_unsharded
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        ic = nb.plummer_2d(32768, 42)
+        sim = DistributedSimulation(ic, eps=0.05, device_index=0, protocol="tune", driver="tune", rehearse_single_rank=True, tune_steps=4,
+                                    tune_dt=1e-3)
+        sim.advance(3, 1e-3)
+        check = compare_with_unsharded(sim.owned_rows(), sim.plan, lambda: sim.reference_rows(ic, 3, 1e-3), 3)
+        out = {"tuning": sim.tuning, "protocol": sim.protocol, "driver": sim.driver, "check": check,
+               "sharded_protocol": int(sim.sim.shard_protocol)}
+        sim.close()
+        (Path(out_dir) / "rehearsal.json").write_text(json.dumps(out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rehearsal_of_the_whole_start_up_through_rccl(tmp_path):
+    """Everything a node run's start-up executes, on the one rank a one-GPU box allows, through RCCL itself
+    (`rehearse_single_rank`: NB_FLAG_SHARD_SINGLE handles, one-rank collectives): 4 protocols x 2 step loops timed, every
+    candidate validated against one unsharded handle, every C-loop candidate compared with the torch-driven trial of its
+    protocol — with one rank every sum is a copy, so they must be BIT-IDENTICAL — and the chosen configuration checked again."""
+    import json
+
+    import torch.multiprocessing as mp
+    from nbodysim_amd import _lib as L
+    mp.spawn(_rehearsal_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = json.loads((tmp_path / "rehearsal.json").read_text())
+    t = out["tuning"]
+    names = set(t["ms_per_step"])
+    assert {"allgather", "allreduce", "symmetric", "c:allgather", "c:allreduce", "c:symmetric"} <= names and t["failed"] == {}
+    timed = {k for k, v in t["ms_per_step"].items() if v is not None}
+    assert {"allgather", "allreduce", "symmetric", "c:allgather", "c:allreduce", "c:symmetric"} <= timed
+    for k in timed:
+        v = t["validation"][k]
+        assert v["ok"] is True and v["max_rel_pos"] < 1e-5 and v["max_rel_vel"] < 1e-5, (k, v)
+        if k.startswith("c:"):
+            assert v["vs_torch_loop"] == "bit-identical", (k, v)
+    assert t["chosen"] in timed and out["check"]["ok"] is True and out["check"]["max_rel_pos"] < 1e-5
+    assert out["sharded_protocol"] in (L.NB_SHARD_ALLGATHER, L.NB_SHARD_SYMMETRIC, L.NB_SHARD_ALLREDUCE)     # a sharded protocol ran, with one rank
+    assert out["driver"] == ("c" if t["chosen"].startswith("c:") else "torch")
