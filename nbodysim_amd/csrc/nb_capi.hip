@@ -615,6 +615,8 @@ static int choose_mass_scaling(nb_sim *s)
     void *saved = nullptr, *ref = nullptr;
     uint32_t *out = nullptr;
     int rc = NB_OK;
+    const bool prof = s->prof;
+    s->prof = false;                  // the check's two force launches are not the caller's: keep them out of nb_profile_read
     auto body = [&]() -> int {
         HIPCHK(hipMalloc(&saved, bytes));
         HIPCHK(hipMalloc(&ref, bytes));
@@ -645,6 +647,7 @@ static int choose_mass_scaling(nb_sim *s)
         return NB_OK;
     };
     rc = body();
+    s->prof = prof;
     if (rc) s->mass_scaled = false;
     (void)hipFree(saved); (void)hipFree(ref); (void)hipFree(out);
     s->acc_valid = false;

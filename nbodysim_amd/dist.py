@@ -685,10 +685,14 @@ class DistributedSimulation:
             self.close()
 
         log = (lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush())) if self.plan.rank == 0 else None
-        prefer = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather", "auto")
+        # near-ties (within 1 %) go to the earlier name: the protocol order below, and within a protocol the library's C loop before the
+        # torch-driven one — a C-loop candidate that is still in the race HAS reproduced the torch-driven trial, and north_star wants
+        # the host loop in C; it loses only where it is measurably slower
+        order = ("symmetric", "symmetric+late", "symmetric-late", "allreduce", "allgather", "auto")
+        prefer = tuple(x for k in order for x in ("c:" + k, k))
         failed: Dict[str, str] = {}
         best, job = time_candidates(list(cands), run_one, self.group, self.deadline_s, self.plan.rank,
-                                    prefer=prefer + tuple("c:" + k for k in prefer), log=log, cleanup=cleanup, failed=failed)
+                                    prefer=prefer, log=log, cleanup=cleanup, failed=failed)
         self.tuning = {"steps": steps, "ms_per_step": {k: (v * 1e3 if np.isfinite(v) else None) for k, v in job.items()}, "chosen": best,
                        "order": list(cands), "deadline_s_per_candidate": self.deadline_s,
                        "validation": {k: {a: b for a, b in v.items() if a in ("max_rel_pos", "max_rel_vel", "steps", "ok", "vs_torch_loop", "replicas", "error")}
