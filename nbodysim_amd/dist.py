@@ -444,6 +444,7 @@ class DistributedSimulation:
         self.deadline_s = float(deadline_s)     # per start-up candidate and for forming the C-level communicator; <= 0: none
         self.verify = bool(verify)
         self._broken: Optional[BaseException] = None   # first failure of a compute call of the torch-driven loop (see step())
+        self._defer_errors = False                     # start-up trials: wait() keeps such a failure pending until the trial's collectives are through
 
         extra: dict = {}
         if self._multi and (protocol == "tune" or driver == "tune"):
@@ -642,42 +643,60 @@ class DistributedSimulation:
                 if "not eligible" not in str(e) and "communicator could not be formed" not in str(e):
                     raise
                 return float("inf")
-            self.advance(2, dt)
-            self.wait()
-            self.dist.barrier(group=self.group)
-            t0 = time.perf_counter()
-            self.advance(steps, dt)
-            self.wait()
-            self.dist.barrier(group=self.group)
-            per_step = (time.perf_counter() - t0) / steps
-            v: dict = {}
-            if self.replicated and not self.replicas_identical():
-                per_step, v["replicas"] = float("inf"), "diverged: this transport does not hand every rank the same sum"
-            if self.verify:
-                got: list = []
-                v.update(compare_with_unsharded(self.owned_rows(), self.plan, unsharded, trial_steps, group=self.group, full_out=got))
-                if not v["ok"]:
-                    per_step = float("inf")
-                elif d == "c" and name[2:] in states:             # the library's loop against the torch-driven loop, same protocol
-                    same = bool(np.array_equal(got[0], states[name[2:]]))
-                    rel = 0.0 if same else max(max_rel(got[0][:, :got[0].shape[1] // 2], states[name[2:]][:, :got[0].shape[1] // 2])[0],
-                                               max_rel(got[0][:, got[0].shape[1] // 2:], states[name[2:]][:, got[0].shape[1] // 2:])[0])
-                    reducing = self.symmetric or self.replicated
-                    v["vs_torch_loop"] = ("bit-identical" if same else
-                                          f"differs by {rel:.2e} (" + ("another order of the RCCL sum: accepted below 1e-6" if reducing and rel <= 1e-6
-                                                                       else "REJECTED: the same exchange must give the same bits") + ")")
-                    if not same and not (reducing and rel <= 1e-6):
+            # From here to the end of the trial EVERY rank walks the same sequence of collectives (steps, barriers, the replica check,
+            # the validation gather), whatever happens to its own compute calls: a failed launch is kept pending (_defer_errors) and the
+            # rank goes on issuing its collectives with garbage, so that no peer is left inside one; it is raised once the trial's last
+            # collective is through, and time_candidates lets the ranks agree on it.
+            self._defer_errors = True
+            try:
+                self.advance(2, dt)
+                self.wait()
+                self.dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                self.advance(steps, dt)
+                self.wait()
+                self.dist.barrier(group=self.group)
+                per_step = (time.perf_counter() - t0) / steps
+                v: dict = {}
+                if self.replicated and not self.replicas_identical():
+                    per_step, v["replicas"] = float("inf"), "diverged: this transport does not hand every rank the same sum"
+                if self.verify:
+                    got: list = []
+                    try:                                              # a rank whose compute failed has no state worth reading (its handle
+                        rows = self.owned_rows() if self._broken is None else None       # may sit inside a split step) — but it still takes
+                    except L.NBodyError as e:                         # part in the gather below, with zeros
+                        rows, self._broken = None, (self._broken or e)
+                    if rows is None:
+                        rows = np.zeros((self.plan.i_count, 2 * (3 if self._width == 4 else 2)))
+                    v.update(compare_with_unsharded(rows, self.plan, unsharded, trial_steps, group=self.group, full_out=got))
+                    if not v["ok"]:
                         per_step = float("inf")
-                elif d == "c":
-                    v["vs_torch_loop"] = "no torch-driven trial of this protocol to compare with; judged on the unsharded check alone"
-                if np.isfinite(per_step):
-                    states[name] = got[0]
+                    elif d == "c" and name[2:] in states:             # the library's loop against the torch-driven loop, same protocol
+                        same = bool(np.array_equal(got[0], states[name[2:]]))
+                        half = got[0].shape[1] // 2
+                        rel = 0.0 if same else max(max_rel(got[0][:, :half], states[name[2:]][:, :half])[0],
+                                                   max_rel(got[0][:, half:], states[name[2:]][:, half:])[0])
+                        reducing = self.symmetric or self.replicated
+                        v["vs_torch_loop"] = ("bit-identical" if same else
+                                              f"differs by {rel:.2e} (" + ("another order of the RCCL sum: accepted below 1e-6" if reducing and rel <= 1e-6
+                                                                           else "REJECTED: the same exchange must give the same bits") + ")")
+                        if not same and not (reducing and rel <= 1e-6):
+                            per_step = float("inf")
+                    elif d == "c":
+                        v["vs_torch_loop"] = "no torch-driven trial of this protocol to compare with; judged on the unsharded check alone"
+                    if np.isfinite(per_step):
+                        states[name] = got[0]
+            finally:
+                self._defer_errors = False
+            pending, self._broken = self._broken, None
             validation[name] = v
             if not np.isfinite(per_step) and self.plan.rank == 0:
                 sys.stderr.write(f"[tune] rank 0: {name} DISQUALIFIED: " + ", ".join(f"{a}={b}" for a, b in v.items() if a in
                                  ("max_rel_pos", "max_rel_vel", "worst_particle", "worst_rank", "error", "vs_torch_loop", "replicas")) + "\n")
                 sys.stderr.flush()
             self.close()
+            if pending is not None:
+                raise pending
             return per_step
 
         def cleanup(name: str) -> None:
@@ -810,7 +829,7 @@ class DistributedSimulation:
                 self._pending.wait()
                 self._pending = None
         self.stream.synchronize()
-        if self._broken is not None:              # a compute call failed earlier; its collectives were still issued (_compute)
+        if self._broken is not None and not self._defer_errors:   # a compute call failed earlier; its collectives were still issued (_compute)
             err, self._broken = self._broken, None
             raise err
 
