@@ -438,7 +438,8 @@ def test_a_compute_failure_on_one_rank_inside_a_candidate_strands_nobody(tmp_pat
         t = rep["tuning"]
         assert t["ms_per_step"]["symmetric"] is None and "symmetric" in t["failed"], (r, t)
         assert ("injected" in t["failed"]["symmetric"]) if r == 1 else (t["failed"]["symmetric"] == "failed on another rank")
-        assert all(v is not None for k, v in t["ms_per_step"].items() if k != "symmetric"), t["ms_per_step"]      # the others ran afterwards
+        # the others ran afterwards (the same split with the late items flipped is not tried once the plain one is out)
+        assert t["ms_per_step"]["allgather"] is not None and t["ms_per_step"]["allreduce"] is not None and t["ms_per_step"]["symmetric+late"] is None
     pos = np.concatenate([np.load(tmp_path / f"fpos_{r}.npy") for r in range(world)])
     ref, _, _ = _reference(n, 4, "fp32")
     assert _rel(pos, ref.astype(np.float64)) < 2e-6
