@@ -732,6 +732,9 @@ void sym_chunks2(const float2 *__restrict__ pos, const float *__restrict__ mass,
 // cross-wave combine (no barrier inside the sweep), and an item's stationary row is 4 KiB instead of 16.  The four
 // waves' stationary sums are added once, at the end, through LDS in wave order.  Price: four times the travelling
 // partials per pair (one per 512 x 64 instead of 2048 x 64 pairs), which is why large systems keep the classic form.
+#ifndef NB_STAMP
+#define NB_STAMP(k)          // measurement hook of tools/sym_timeline.hip (stamps inside a workgroup); nothing in the library
+#endif
 template <int RSQ, int MM, bool PAIRS = false, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
@@ -764,6 +767,7 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
         xi[p] = (v2f){p0.x, p1.x}; yi[p] = (v2f){p0.y, p1.y}; mi[p] = (v2f){m0, m1};
         ax[p] = (v2f){0.f, 0.f}; ay[p] = (v2f){0.f, 0.f};
     }
+    NB_STAMP(1);                                                  // (tools/sym_timeline.hip only; empty in the product)
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
     if constexpr (PAIRS) {
         if (diag) sym_chunks2<RSQ, MM, true, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
@@ -773,6 +777,7 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
         else      sym_chunks<RSQ, MM, false, WS, WT>(pos, mass, sigma, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red);
     }
 
+    NB_STAMP(2);
     float2 *__restrict__ out = slab_s + (size_t)s_row * SB;
     if constexpr (WS) {
         // the 4 waves hold partial sums of the SAME 512 particles (each over its own chunks): add them in wave order;

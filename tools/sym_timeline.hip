@@ -11,6 +11,12 @@
 //   build/sym_timeline [n=25000] [tile=512|2048] [L=0] [masses=1: 0 equal | 1 individual | 2 individual, mass-scaled body] [pairs=0] [reps=20] [shift=0] [stagger=0]
 //   stagger = k > 0 (experiment): among the first `stagger` items of the list every other adjacent pair of symmetric items of the same
 //   tile is MERGED into one item of twice the chunks, so that the workgroups that start together on a CU no longer end together
+// stamps INSIDE a workgroup (the body calls NB_STAMP(1) once the stationary particles are loaded, NB_STAMP(2) after the sweep of
+// the item's chunks): wave 0 waits for its outstanding loads and records the real-time counter
+#include <hip/hip_runtime.h>
+__device__ unsigned long long *g_inner = nullptr;          // [workgroups][2]
+#define NB_STAMP(k) do { if (g_inner && threadIdx.x < 64u) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+                         if (threadIdx.x == 0u) g_inner[(size_t)blockIdx.x * 2u + (k) - 1u] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #include "nb_kernels.hip.h"
 
 #include <algorithm>
@@ -30,10 +36,15 @@ struct Stamp { unsigned long long t0, t1, c0, c1; unsigned hw_id, xcc_id; };
 
 template <int MM, bool PAIRS, bool WS>
 __global__ __launch_bounds__(BLOCK, NB_SYM_WAVES)
-void stamped(const float2 *pos, const float *mass, const float *sigma, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st, uint32_t shift)
+void stamped(const float2 *pos, const float *mass, const float *sigma, const SymItem *items, float2 *slab_s, float2 *slab_r, uint32_t n, float eps2, float um, Stamp *st, uint32_t shift,
+             uint32_t delay_ticks, uint32_t delay_div)
 {
     if (blockIdx.x < shift) return;                     // `shift` idle workgroups in front: item i runs as workgroup i + shift (moves every item to another XCD)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    if (delay_ticks && blockIdx.x < 1024u) {            // experiment: de-phase the workgroups of the first resident wave (k = 0..3 by index / delay_div)
+        const unsigned long long until = t0 + (unsigned long long)delay_ticks * ((blockIdx.x / delay_div) & 3u);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     force_sym_f32_body<RSQ_EXACT, MM, PAIRS, WS, true>(pos, mass, sigma, items[blockIdx.x - shift], slab_s, slab_r, n, eps2, um);   // write-through slab stores, like the product
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) {
@@ -55,7 +66,9 @@ int main(int argc, char **argv)
     const bool pairs = argc > 5 ? atoi(argv[5]) != 0 : false;
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
     const uint32_t shift = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;
-    const int stagger = argc > 8 ? atoi(argv[8]) : 0;            // > 0: desynchronise the workgroups that share a CU (see below)
+    const int stagger = argc > 8 ? atoi(argv[8]) : 0;
+    const uint32_t delay_ticks = argc > 9 ? (uint32_t)atoi(argv[9]) : 0u;      // experiment: first-wave workgroup k of a CU starts k x this many 10-ns ticks late
+    const uint32_t delay_div = argc > 10 ? (uint32_t)atoi(argv[10]) : 256u;    // ... with k = (index / delay_div) mod 4            // > 0: desynchronise the workgroups that share a CU (see below)
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
 
@@ -94,9 +107,13 @@ int main(int argc, char **argv)
     CK(hipMemcpy(sigma, hsig.data(), n * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(items, pl.items.data(), pl.items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     const uint32_t grid = (uint32_t)pl.items.size();
+    unsigned long long *inner_dev = nullptr;
+    CK(hipMalloc(&inner_dev, (size_t)(grid + shift) * 2 * sizeof(unsigned long long)));
+    CK(hipMemset(inner_dev, 0, (size_t)(grid + shift) * 2 * sizeof(unsigned long long)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_inner), &inner_dev, sizeof inner_dev));
     const float eps2 = 1e-4f, um = 1.0f / n;
     auto launch = [&]() {
-#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid + shift, BLOCK>>>(pos, mass, sigma, items, ss, sr, n, eps2, um, st, shift)
+#define GO(MMV, PR, WSV) stamped<MMV, PR, WSV><<<grid + shift, BLOCK>>>(pos, mass, sigma, items, ss, sr, n, eps2, um, st, shift, delay_ticks, delay_div)
         if (mass_mode == 2) { if (tile == SYM_SB_WS) GO(MM_SCALED, false, true); else GO(MM_SCALED, false, false); return; }
         if (tile == SYM_SB_WS) { if (general) { if (pairs) GO(MM_GENERAL, true, true); else GO(MM_GENERAL, false, true); }
                                  else         { if (pairs) GO(MM_UNIFORM, true, true); else GO(MM_UNIFORM, false, true); } }
@@ -220,15 +237,51 @@ int main(int argc, char **argv)
         printf("  residency, mean over CUs (us with k workgroups resident):");
         for (int k = 0; k <= 5; ++k) printf("  %d: %.1f", k, held[k] / ev.size());
         printf("\n  busiest CU, its workgroups (start-end us):");
-        std::vector<std::pair<double, double>> w;
+        std::vector<std::pair<std::pair<double, double>, double>> w;      // (start, end), shader clock in MHz while it ran
         for (uint32_t i = 0; i < grid; ++i) {
             const Stamp &q = hs[i];
             const unsigned cu = (q.xcc_id & 0xf) << 16 | ((q.hw_id >> 13) & 0x7) << 8 | ((q.hw_id >> 8) & 0xf);
-            if (cu == busiest) w.push_back({(q.t0 - tmin) * 0.01, (q.t1 - tmin) * 0.01});
+            if (cu == busiest) w.push_back({{(q.t0 - tmin) * 0.01, (q.t1 - tmin) * 0.01}, (double)(q.c1 - q.c0) / (double)(q.t1 - q.t0 + 1) * 100.0});
         }
         std::sort(w.begin(), w.end());
-        for (auto &x : w) printf(" %.1f-%.1f", x.first, x.second);
+        for (auto &x : w) printf(" %.1f-%.1f@%.0f", x.first.first, x.first.second, x.second);
+        printf("\n  ... the indices of its first-round workgroups:");
+        for (uint32_t i = 0; i < grid; ++i) {
+            const Stamp &q = hs[i];
+            const unsigned cu = (q.xcc_id & 0xf) << 16 | ((q.hw_id >> 13) & 0x7) << 8 | ((q.hw_id >> 8) & 0xf);
+            if (cu == busiest && (q.t0 - tmin) * 0.01 < 1.0) printf(" %u", i);
+        }
         printf("\n");
+        // shader clock by start time: do the workgroups of the first round run slower (clock ramp after the gap between launches)?
+        double c_first = 0, c_rest = 0; size_t n_first = 0, n_rest = 0;
+        for (uint32_t i = 0; i < grid; ++i) {
+            const Stamp &q = hs[i];
+            if (q.t1 <= q.t0 + 100) continue;
+            const double mhz_i = (double)(q.c1 - q.c0) / (double)(q.t1 - q.t0) * 100.0;
+            if ((q.t0 - tmin) * 0.01 < 1.0) { c_first += mhz_i; ++n_first; } else { c_rest += mhz_i; ++n_rest; }
+        }
+        {   // inside a workgroup: start -> stationary particles loaded -> sweep done -> end, first round against the later ones
+            std::vector<unsigned long long> hin((size_t)(grid + shift) * 2);
+            CK(hipMemcpy(hin.data(), inner_dev, hin.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<double> pro[2], swp[2], epi[2];
+            for (uint32_t i = 0; i < grid; ++i) {
+                const Stamp &q = hs[i];
+                const unsigned long long s1 = hin[(size_t)(i + shift) * 2], s2 = hin[(size_t)(i + shift) * 2 + 1];
+                if (!s1 || !s2 || pl.items[i].diag) continue;
+                const int late = (q.t0 - tmin) * 0.01 < 1.0 ? 0 : 1;
+                pro[late].push_back((s1 - q.t0) * 0.01); swp[late].push_back((s2 - s1) * 0.01); epi[late].push_back((q.t1 - s2) * 0.01);
+            }
+            for (int k = 0; k < 2; ++k) {
+                if (pro[k].empty()) continue;
+                std::sort(pro[k].begin(), pro[k].end()); std::sort(swp[k].begin(), swp[k].end()); std::sort(epi[k].begin(), epi[k].end());
+                auto med = [](const std::vector<double> &v) { return v[v.size() / 2]; };
+                printf("  inside a workgroup, %s (%zu symmetric items): stationary loads %.2f us (p90 %.2f) | sweep %.2f us (p90 %.2f) | combine + store %.2f us (p90 %.2f)\n",
+                       k == 0 ? "FIRST round" : "later rounds", pro[k].size(), med(pro[k]), pro[k][(size_t)(0.9 * pro[k].size())],
+                       med(swp[k]), swp[k][(size_t)(0.9 * swp[k].size())], med(epi[k]), epi[k][(size_t)(0.9 * epi[k].size())]);
+            }
+        }
+        printf("  shader clock of the workgroups that start in the first microsecond: %.0f MHz (%zu), of the later ones: %.0f MHz (%zu)\n",
+               n_first ? c_first / n_first : 0.0, n_first, n_rest ? c_rest / n_rest : 0.0, n_rest);
     }
     return 0;
 }
