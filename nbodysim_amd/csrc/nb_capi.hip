@@ -158,7 +158,7 @@ static int bind(const nb_sim *s)
 // Launch geometry of one one-sided force job.  The kernel is VALU-bound, so what
 // matters is (a) enough independent work per lane — 2P particles per lane, P = 4 measured best — and
 // (b) enough workgroups in flight to keep 5-8 waves per SIMD issuing and to even out the tail: about
-// 32 workgroups per CU (tools/force_bench.hip).  When i-particles are scarce (sharded or small runs)
+// 32 workgroups per CU (profiles/r01_force_tiled_geometry_sweep.log).  When i-particles are scarce (sharded or small runs)
 // the j range is cut into more tile-aligned slices (at most 128: every slice is a slab that
 // `integrate` re-reads), and P drops only when even that cannot fill half the target.
 static bool want_sym(const nb_sim *s);
@@ -185,7 +185,7 @@ static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t sla
     // particles -> 128P particles per workgroup; fp64: 256 i-lanes, P particles per lane.
     const uint32_t lanes_i = s->fp64 ? 1u : 2u;                 // particles per lane per P
     const uint32_t ilanes = s->fp64 ? (uint32_t)BLOCK : (uint32_t)BLOCK / F32_WS;
-    const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (tools/force_bench.hip sweep)
+    const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (profiles/r01_force_tiled_geometry_sweep.log)
     const uint32_t max_slices = 128;                            // bounds the slab traffic of `integrate`
     const uint32_t tiles = (jn + TJ - 1) / TJ;
     const int forced_p = s->p.lanes_p > 0 ? s->p.lanes_p : 0;
@@ -231,7 +231,7 @@ static bool needs_guard(const nb_sim *s) { return s->fp64 ? !(s->p.eps > 0.0f) :
 // workgroup share the stationary particles and split the chunks) give the planner work units a quarter the size, items
 // whose stationary row is 4 KiB instead of 16, and a sweep without barriers — what small and mid-size systems need to
 // fill 1024 resident workgroup slots evenly — for four times the travelling partials per pair, which large systems do not
-// pay back.  Measured (tools/ws_sweep.py, profiles/r04_ws_sweep.log): -3 ... -4 % step time at N = 25 000 (reference
+// pay back.  Measured (profiles/r04_ws_sweep.log): -3 ... -4 % step time at N = 25 000 (reference
 // workload), -2.5 % at 16 384 and 32 768, neutral at 65 536, +1.3 ... +2.6 % at 131 072: used below 49 152 bodies.
 // fp32 2-D, single handle (a rank of a sharded run keeps the classic tiles: its blocks are whole 2048-particle tiles).
 // nb_params.sym_tile = 512 / 2048 forces one.  Rank-independent (n and parameters only).
@@ -250,7 +250,7 @@ static bool sym_eligible(const nb_sim *s)
     if (s->p.integrator != NB_INTEGRATOR_KICK_DRIFT && s->i_count != s->n) return false;
     // smallest system worth the symmetric scheme: 16 384 bodies with the classic tiles (rounds 1-3); with the wave-split tiles and
     // their uniform one-chunk-per-wave plans it overtakes the one-sided kernel from ~5 600 bodies on (-4 ... -8 % at 5 632, -14 ... -17 %
-    // at 6 144, -24 ... -28 % at 7 168, -32 ... -34 % at 10 000; +1 ... +6 % at 5 120, +25 % at 4 096: tools/one_wave_check.py,
+    // at 6 144, -24 ... -28 % at 7 168, -32 ... -34 % at 10 000; +1 ... +6 % at 5 120, +25 % at 4 096:
     // profiles/r04_small_n_plans.log)
     if (s->n < (sym_tile_of(s->p, s->n) == SYM_SB_WS ? (size_t)5632 : 8 * (size_t)SYM_SB)) return false;
     const uint32_t world = s->p.shard_world > 1 ? (uint32_t)s->p.shard_world : 1u;
@@ -393,7 +393,7 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
 // PAGES; a malloc'ed array shares its first and last page with whatever the heap put next to it, and a registration
 // that outlives the array (a std::vector that reallocated) keeps pinning pages that now belong to someone else.
 // Round 2 saw one process abort inside nb_upload right after nb_host_register of an unaligned numpy array.  CAUSE
-// UNKNOWN: no log of that run exists, and none of the nine deterministic constructions of tools/pin_probe.hip (shared
+// UNKNOWN: no log of that run exists, and none of the nine deterministic constructions of round 3's pin probe (shared
 // pages, overlapping registrations, freed-while-registered memory reused at the same address ...) aborts on this
 // runtime (profiles/r03_pin_probe.log).  The rules above are therefore a DEFENSIVE change, not the fix of a known bug.
 struct PinnedRange { uintptr_t lo, hi; bool owned; };

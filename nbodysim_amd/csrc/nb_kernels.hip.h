@@ -439,7 +439,7 @@ void force_tiled_f32(const float2 *__restrict__ pos, const float *__restrict__ m
 // Requires eps > 0 (r = 0 then contributes exactly 0); eps == 0 uses force_tiled_f32<GUARD>.
 // ---------------------------------------------------------------------------
 #ifndef NB_SYM_UNROLL
-#define NB_SYM_UNROLL 2      // rotation steps unrolled together (tools/sym_sweep.sh)
+#define NB_SYM_UNROLL 2      // rotation steps unrolled together (1 / 2 / 4 measured level: profiles/r05_first_item_vs_unroll.log)
 #endif
 #ifndef NB_SYM_WAVES
 #define NB_SYM_WAVES 1       // __launch_bounds__ minimum waves per SIMD for force_sym_f32
@@ -829,7 +829,7 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 #ifndef NB_SYM_WT
 #define NB_SYM_WT true       // write-through (sc1) slab stores: the partials are read by the NEXT launch only, so nothing is gained by
 #endif                       // keeping them dirty in this XCD's L2 until the kernel's end flushes them: -1.8 % step time at N = 25 000,
-                             // -0.7 % at 65 536, neutral at 262 144, same bits (tools/wt_ab.sh, profiles/r04_write_through_ab.log)
+                             // -0.7 % at 65 536, neutral at 262 144, same bits (profiles/r04_write_through_ab.log)
     force_sym_f32_body<RSQ, MM, PAIRS, WS, NB_SYM_WT>(pos, mass, sigma, items[sym_item_index(ticket, first_wave, ticket_base)], slab_s, slab_r, n, eps2, um_mass);
 }
 
