@@ -819,7 +819,10 @@ def main() -> None:
                                  uniform_mass=not args.general_mass, mass_scaling=scaling)
 
         status = run_sharded(args, ic, n, world, rank, make_sim, make_reference, torch.cuda.synchronize, dist.barrier)
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        # the line is out; tearing the process group down must not turn a finished run into a hang (a peer that left early)
+        with Watchdog(60.0, "destroying the process group after the run", rank=rank, exit_fn=lambda _code: os._exit(status)):
+            dist.destroy_process_group()
         if status:
             raise SystemExit(status)
         return
