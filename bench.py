@@ -677,6 +677,12 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
                 safe_m = timed_region(sim, args, world, rank, barrier, device_sync, reference, phase, "safe first: ", check)
                 safe_line = make_line(args, n, world, sim, safe_m)          # every rank builds it (cheap); rank 0 would print it
                 state["safe_line"] = safe_line
+                if rank == 0:                                                # progress on stderr: what a failed node run's log shows first
+                    sys.stderr.write(f"[bench] safe first (all-gather, torch-driven): {safe_line['ms_per_step']:.3f} ms/step, parity_check "
+                                     f"pos {safe_m['parity']['max_rel_pos']:.2e} vel {safe_m['parity']['max_rel_vel']:.2e} ok={safe_m['parity']['ok']}; "
+                                     "kept as the fallback line\n" if safe_m["parity"] else
+                                     f"[bench] safe first (all-gather, torch-driven): {safe_line['ms_per_step']:.3f} ms/step (self-check off)\n")
+                    sys.stderr.flush()
             except ParityError as e:
                 # the plainest protocol is wrong on this node: nothing later can be trusted to be judged by the same check either,
                 # but the faster candidates are still tried — each is validated on its own
@@ -690,6 +696,9 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
         phase["now"] = f"creating the sharded simulation (protocol {args.protocol}, driver {args.driver})"
         sim = make_sim("allgather" if args.no_symmetry else args.protocol, args.driver)
         state["tuning"] = getattr(sim, "tuning", None)        # what the start-up timing found, for the fallback line too
+        if rank == 0:
+            sys.stderr.write(f"[bench] running with protocol {getattr(sim, 'protocol', '?')}, step loop {getattr(sim, 'driver', '?')}: {driver_reason(sim)}\n")
+            sys.stderr.flush()
         m = timed_region(sim, args, world, rank, barrier, device_sync, reference, phase, "", check)
         sustained = None
         if not args.no_sustained:
