@@ -89,12 +89,13 @@ def case(name, n, world, steps=6, allreduce=False, dims=2, profile=False, **kw):
     b = make_handles(ic, world, allreduce, dims=dims, **kw)
     got, info, phases = via_comm(b, steps, profile)
     frames = [s.frame for s in b]
+    late = [int(s.sym_info()["items_late"]) for s in b]
     for s in b:
         s.close()
     same = all(np.array_equal(bits(g[f]), bits(r[f])) for g, r in zip(got, ref) for f in ("pos", "vel", "acc"))
     worst = max(float(np.max(np.abs(g["pos"] - r["pos"]))) for g, r in zip(got, ref))
     out = {"case": name, "n": n, "world": world, "protocol": proto, "comm": info, "frames": frames, "bit_identical": bool(same),
-           "max_abs_pos_diff": worst, "owned": [int(g.shape[0]) for g in got]}
+           "max_abs_pos_diff": worst, "owned": [int(g.shape[0]) for g in got], "late_items": late}
     if phases:
         out["phases"] = phases
     print(json.dumps(out), flush=True)
@@ -147,6 +148,10 @@ def main():
     case("allreduce fp64 world 4", 32768, 4, allreduce=True, precision="fp64")
     case("symmetric 3-D fp32 world 2", 16384, 2, dims=3)
     case("allgather 3-D fp32 world 4", 8192, 4, dims=3, symmetry=False)
+    # the driver's node run at its largest: N = 262 144 over EIGHT ranks — the plan the library builds there (12 chunk pairs per item,
+    # the late items ON by default from 8 ranks), the symmetric and the all-reduce protocol, 4 steps
+    case("symmetric fp32 world 8 headline", 262144, 8, steps=4)
+    case("allreduce fp32 world 8 headline", 262144, 8, steps=4, allreduce=True)
     failure_case()
 
 
