@@ -86,3 +86,36 @@ def test_the_line_says_which_host_loop_won_and_why():
     s.tuning = None
     assert "named on the command line" in b.driver_reason(s)
     assert b.parse_args([]).driver == "tune" and b.parse_args([]).protocol == "tune"        # the defaults of a node run
+
+
+def test_unsharded_reference_steps_forward_caches_and_restarts():
+    """bench.UnshardedReference: rank 0's checker advances ONE handle forward, caches the rows per step count, and starts a fresh
+    handle only when asked for an earlier state than it holds."""
+    import numpy as np
+    b = load_bench()
+    made = []
+
+    class Handle:
+        def __init__(self):
+            self.frame, self.closed = 0, False
+            made.append(self)
+
+        def advance(self, k, dt):
+            assert k >= 0
+            self.frame += k
+
+        def sync(self):
+            out = np.zeros(3, dtype=[("pos", np.float32, 2), ("vel", np.float32, 2)])
+            out["pos"][:, 0] = self.frame
+            return out
+
+        def close(self):
+            self.closed = True
+    ref = b.UnshardedReference(Handle)
+    assert ref.rows(3)[0, 0] == 3 and len(made) == 1
+    assert ref.rows(8)[0, 0] == 8 and len(made) == 1 and made[0].frame == 8          # stepped forward, same handle
+    assert ref.rows(3)[0, 0] == 3 and len(made) == 1                                  # cached
+    assert ref.rows(5)[0, 0] == 5 and len(made) == 2 and made[0].closed               # earlier than held and not cached: a fresh handle
+    assert ref.rows(5).shape == (3, 4)
+    ref.close()
+    assert made[1].closed
