@@ -350,3 +350,31 @@ def test_config2_lds_tiled_kernel_at_65536_vs_fp64_direct(nbo):
             got = sim.sync()
         assert max_rel(got["pos"], pos64) < 1e-5 and max_rel(got["vel"], vel64) < 1e-5, symm
         assert np.max(np.abs(got["acc"].astype(np.float64) - acc64)) < 2e-5 * np.max(np.abs(acc64)), symm
+
+
+@pytest.mark.parametrize("n,precision", [(1048576, "fp32"), (262144, "fp32"), (262144, "fp64")])
+def test_exact_scaling_laws_hold_bit_for_bit_at_full_size(n, precision):
+    """Size-independent properties at BASELINE's full sizes (config 4's million bodies on one handle; configs 3 and 5), no oracle
+    needed: in binary floating point a scaling by a power of two is EXACT through every operation of the pair body, so
+      * doubling every mass doubles every acceleration, bit for bit (equal-mass and individual-mass bodies);
+      * doubling every coordinate AND the softening quarters every acceleration, bit for bit (r^2 x 4 keeps the exponent's
+        parity, so the hardware rsqrt returns exactly half; inv^3 x 1/8, times the displacement x 2).
+    A kernel that mixed up a slab row, an item range or a mass anywhere in its 2 GiB of partials would break the identity."""
+    ic = nb.plummer_2d(n, 7)
+    ic["mass"] = np.float32(1.0 / 1048576)                 # a power of two: the equal-mass product um * inv^3 scales exactly too
+
+    def acc_of(b, eps, **kw):
+        with nb.Simulation(b, eps=eps, precision=precision, **kw) as sim:
+            d = sim.describe()
+            return sim.accelerations().copy(), d
+    for kw in (dict(), dict(uniform_mass=False, mass_scaling=False)):        # MM_UNIFORM, then MM_GENERAL (12 + 2, no folding)
+        a1, d1 = acc_of(ic, EPS, **kw)
+        assert "symmetric=1" in d1 and f"uniform_mass={int(not kw)}" in d1 and np.isfinite(a1).all()
+        heavy = ic.copy()
+        heavy["mass"] *= np.float32(2.0)
+        a2, _ = acc_of(heavy, EPS, **kw)
+        assert np.array_equal((a1 * np.float32(2.0)).view(np.uint32), a2.view(np.uint32)), ("mass x 2", kw)
+        wide = ic.copy()
+        wide["pos"] *= np.float32(2.0)
+        a3, _ = acc_of(wide, 2.0 * EPS, **kw)
+        assert np.array_equal((a1 * np.float32(0.25)).view(np.uint32), a3.view(np.uint32)), ("length x 2", kw)
