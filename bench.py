@@ -4,8 +4,16 @@ pair interactions/s of the direct O(N^2) softened-gravity + kick/drift step at
 N = 262 144 (fp32, exact rsqrt, Plummer-2D synthetic data), 1/2/4/8 GPUs.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # typed as is: see "Launching" below
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+Launching.  One process per GPU either way.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank.
+Typed without a launcher, `--gpus N` (N > 1) makes this process the launcher: before it imports torch or touches a
+GPU it starts `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD process (never an exec),
+relays rank 0's one JSON line and the ranks' stderr, forwards SIGTERM / SIGINT, and returns the children's status.
+Without torch.distributed.run (or with --one-process) ONE process drives N sharded handles, one per device, through
+the library's own RCCL loop (nb_comm_create_all / nb_comm_step), with the same self-check and line.
 
 A "step" = one force evaluation over all N^2 pairs (self pairs included, as the
 kernel evaluates them) + kick + drift.  N is FIXED as GPUs are added (strong
@@ -41,6 +49,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -155,8 +165,11 @@ def sustained_steps(ms_per_step_hint, min_seconds=2.0):
 
 def reduce_max_over_ranks(value, world):
     """MAX of a host float over the ranks of the default process group (the identity for one rank)."""
-    import torch.distributed as dist
-    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return float(value)
+    if not (dist.is_available() and dist.is_initialized()):     # one rank, or one process driving every rank (no process group)
         return float(value)
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -306,11 +319,16 @@ def parse_args(argv=None):
                          "'host code stays in C'); torch = collectives through torch.distributed between the library's split-step calls; "
                          "tune (default) = both are candidates of the start-up timing, and a C-loop candidate may only win after its trial "
                          "reproduced the torch-driven trial of the same protocol bit for bit and passed the unsharded check")
-    ap.add_argument("--deadline", type=float, default=900.0,
+    ap.add_argument("--deadline", type=float, default=420.0,
                     help="seconds the whole multi-GPU run may take before the rank prints the phase it is in and exits with status 3 "
-                         "(a stuck collective must not become a silent hang); 0 = none")
-    ap.add_argument("--candidate-deadline", type=float, default=120.0,
+                         "— or, once the safe-first configuration has been measured, prints THAT line and exits 0 (a stuck collective "
+                         "must not become a silent hang, and must fit inside the driver's own 600 s limit); 0 = none")
+    ap.add_argument("--candidate-deadline", type=float, default=45.0,
                     help="seconds one start-up candidate (or forming the C-level communicator) may take before the same")
+    ap.add_argument("--one-process", action="store_true",
+                    help="N > 1 without a launcher: ONE process drives the N sharded handles (one per device) through the library's own RCCL "
+                         "loop (nb_comm_create_all) instead of starting one child process per GPU; what `--gpus N` falls back to where "
+                         "torch.distributed.run is missing.  With --share-gpu (rehearsal) the handles share GPU 0 and exchange in-process")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s settled-rate measurement after the timed region")
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
@@ -404,11 +422,13 @@ def timed_region(sim, args, world, rank, barrier, device_sync, reference=None, p
     k1, u1 = sim.energy()
     phases_max = None
     if sharded:
-        import torch
-        import torch.distributed as dist
-        from nbodysim_amd.dist import _comm_device
         elapsed = reduce_max_over_ranks(elapsed, world)
-        if phases is not None:   # slowest rank per phase, so an exposed collective on any rank shows
+        if phases is not None and getattr(sim, "world", 0) > 1:       # one process drives every rank: its report is already the slowest handle's
+            phases_max = {k: v for k, v in phases.items() if isinstance(v, float)}
+        elif phases is not None:   # slowest rank per phase, so an exposed collective on any rank shows
+            import torch
+            import torch.distributed as dist
+            from nbodysim_amd.dist import _comm_device
             keys = [k for k, v in phases.items() if isinstance(v, float)]
             pt = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device=_comm_device())
             dist.all_reduce(pt, op=dist.ReduceOp.MAX)
@@ -461,7 +481,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     um = "uniform_mass=1" in inner.describe()
     kernel = ("force_sym" if symmetric else "force_tiled") + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64")
     # force launches per step on this rank: 1 (single GPU) or up to 3 (local + cross + late / local + remote ranges)
-    owned = sim.plan.i_count if sharded else n                        # rank 0's block (ragged splits: ceil(n / world))
+    owned = getattr(sim, "owned_per_rank", sim.plan.i_count) if sharded else n    # rank 0's block (ragged splits: ceil(n / world))
     pairs_this_rank = float(owned) * float(n) * args.steps             # its share of the ordered pairs, whatever the protocol
     if launches and force_ms > 0 and not sharded:
         kern_s = force_ms * 1e-3
@@ -619,6 +639,55 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     return line
 
 
+class StopSignals:
+    """SIGTERM / SIGINT -> ``on_stop(signum)``, called from a watcher THREAD the moment the signal arrives.  A Python-level
+    signal handler only runs when the main thread next executes bytecode — never while it sits inside a collective or a
+    device synchronisation, which is exactly where a run that is being stopped from outside sits.  The C-level handler,
+    however, writes the signal's number to the wake-up descriptor at once (signal.set_wakeup_fd); the thread reads it there.
+    Inactive outside the main thread (signal handlers cannot be installed there)."""
+
+    def __init__(self, on_stop, signals=(signal.SIGTERM, signal.SIGINT)):
+        self.on_stop, self.signals, self.active = on_stop, tuple(signals), False
+
+    def __enter__(self):
+        import socket
+        import threading
+        if threading.current_thread() is not threading.main_thread():
+            return self
+        self.r, self.w = socket.socketpair()
+        self.w.setblocking(False)
+        self.old_fd = signal.set_wakeup_fd(self.w.fileno(), warn_on_full_buffer=False)
+        self.old = {sg: signal.signal(sg, lambda _s, _f: None) for sg in self.signals}
+        self.active = True
+
+        def watch():
+            while True:
+                try:
+                    data = self.r.recv(16)
+                except OSError:
+                    return
+                if not data:
+                    return
+                for b in data:
+                    if b in self.signals:
+                        self.on_stop(int(b))
+        threading.Thread(target=watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.active = False
+            for sg, h in self.old.items():
+                signal.signal(sg, h)
+            signal.set_wakeup_fd(self.old_fd)
+            for sk in (self.w, self.r):
+                try:
+                    sk.close()
+                except OSError:
+                    pass
+        return False
+
+
 def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync, barrier, emit=None) -> int:
     """The whole multi-rank run given the engine (`make_sim(protocol, driver)` -> a DistributedSimulation-shaped object,
     `make_reference()` -> rank 0's unsharded handle); returns the process's exit status.  bench.py's main() calls it with the
@@ -632,7 +701,11 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
     3. If step 2 cannot finish — a candidate hangs (its Watchdog expires), the winner fails its self-check, anything
        raises — the line of step 1 is printed instead, with `fallback` saying why, and the run ends with status 0: the first
        node this meets cannot lose the measurement to an optional faster path.  Only if NOTHING valid was measured does the
-       run end non-zero (3 = deadline, 4 = self-check)."""
+       run end non-zero (3 = deadline, 4 = self-check).  "Valid" = the self-check passed after the warm-up AND after the
+       timed steps: a safe-first run that leaves the tolerance during the K timed steps is not kept as the fallback.
+    4. A stop from outside (SIGTERM / SIGINT: a driver's time limit, a launcher tearing the job down) is one more way not to
+       finish: rank 0 prints the safe-first line it holds, with `fallback.why` naming the signal, and every rank that knows a
+       valid line exists ends with status 0 (StopSignals: it works while the main thread is inside a collective)."""
     import threading
 
     from nbodysim_amd.dist import ParityError, Watchdog
@@ -660,9 +733,22 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
         print_once(line)
         return 0
 
+    def on_stop(signum):
+        """SIGTERM / SIGINT (watcher thread): the same last resort as an expired deadline, then the process ends HERE — the main
+        thread may be inside a collective that will never complete."""
+        name = signal.Signals(signum).name
+        sys.stderr.write(f"[bench] rank {rank}: stopped by {name} (phase: {phase['now']})"
+                         + ("; printing the safe-first line\n" if state["safe_line"] is not None else "; nothing valid has been measured yet\n"))
+        sys.stderr.flush()
+        code = last_resort(f"stopped by {name} before the run could finish")
+        sys.stdout.flush()
+        os._exit(0 if code == 0 else 128 + signum)
+
     Watchdog.last_resort = last_resort
     main_watchdog = Watchdog(args.deadline, "running bench.py", report=lambda: f"phase: {phase['now']}", rank=rank)
     main_watchdog.__enter__()
+    stop_signals = StopSignals(on_stop)
+    stop_signals.__enter__()
     reference = UnshardedReference(make_reference) if (rank == 0 and not args.no_parity_check) else None
     check = not args.no_parity_check
     sim = None
@@ -674,14 +760,26 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             phase["now"] = "safe first: creating the all-gather / torch-driven configuration"
             try:
                 sim = make_sim("allgather", "torch")
+                state["safe_driver"] = "torch" if getattr(sim, "driver", "torch") == "torch" else sim.driver
                 safe_m = timed_region(sim, args, world, rank, barrier, device_sync, reference, phase, "safe first: ", check)
                 safe_line = make_line(args, n, world, sim, safe_m)          # every rank builds it (cheap); rank 0 would print it
-                state["safe_line"] = safe_line
+                # kept only if it is VALID: timed_region raises for a failed check after the warm-up, a failure after the timed steps
+                # is only recorded in parity["ok"] — such a line must not become the fallback (it would be printed with status 0)
+                safe_valid = safe_m["parity"] is None or bool(safe_m["parity"]["ok"])
+                if safe_valid:
+                    state["safe_line"] = safe_line
+                else:
+                    state["safe_failed"] = (f"parity_check failed (allgather protocol, torch loop, after the timed region): "
+                                            f"{safe_m['parity'].get('after_timed_region')}")
                 if rank == 0:                                                # progress on stderr: what a failed node run's log shows first
                     sys.stderr.write(f"[bench] safe first (all-gather, torch-driven): {safe_line['ms_per_step']:.3f} ms/step, parity_check "
                                      f"pos {safe_m['parity']['max_rel_pos']:.2e} vel {safe_m['parity']['max_rel_vel']:.2e} ok={safe_m['parity']['ok']}; "
-                                     "kept as the fallback line\n" if safe_m["parity"] else
+                                     + ("kept as the fallback line\n" if safe_valid else "NOT kept: it left the tolerance during the timed steps\n")
+                                     if safe_m["parity"] else
                                      f"[bench] safe first (all-gather, torch-driven): {safe_line['ms_per_step']:.3f} ms/step (self-check off)\n")
+                    if safe_valid:      # the measurement itself, on stderr, the moment it exists: even a SIGKILL leaves it in the log
+                        sys.stderr.write("[bench] safe-first line (stdout gets ONE line at the end; this copy is for the log): "
+                                         + json.dumps({k: safe_line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}) + "\n")
                     sys.stderr.flush()
             except ParityError as e:
                 # the plainest protocol is wrong on this node: nothing later can be trusted to be judged by the same check either,
@@ -710,7 +808,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
         line = make_line(args, n, world, sim, m, sustained)
         if safe_m is not None:
-            line["config"]["safe_first"] = {"protocol": "allgather", "driver": "torch", "ms_per_step": safe_m["elapsed"] / args.steps * 1e3,
+            line["config"]["safe_first"] = {"protocol": "allgather", "driver": state.get("safe_driver", "torch"), "ms_per_step": safe_m["elapsed"] / args.steps * 1e3,
                                             "value": float(n) * float(n) * args.steps / safe_m["elapsed"],
                                             "parity_check": {k: safe_m["parity"][k] for k in ("max_rel_pos", "max_rel_vel", "ok")} if safe_m["parity"] else None,
                                             "note": "north_star's plain all-gather protocol, torch-driven: measured first (same W + K steps), kept as the "
@@ -750,9 +848,161 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             if reference is not None:
                 reference.close()
         finally:
+            stop_signals.__exit__(None, None, None)
             main_watchdog.__exit__(None, None, None)
             Watchdog.last_resort = None
     return status
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` typed without a launcher (N > 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def torchrun_available() -> bool:
+    """Is torch.distributed.run there to start the ranks with?  Looked up ON DISK: the launching process imports neither
+    torch nor anything else that could touch a GPU (find_spec of a top-level name does not import it)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return False
+    return bool(spec and spec.submodule_search_locations and
+                any((Path(d) / "distributed" / "run.py").exists() for d in spec.submodule_search_locations))
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _die_with_parent():
+    """preexec of the launcher child (Linux): SIGTERM when the launching process dies — however it dies, a SIGKILL by the
+    driver's own time limit included — so that no rank is left running on a GPU behind a dead bench.py."""
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)      # PR_SET_PDEATHSIG
+    except Exception:   # noqa: BLE001 - a convenience, never a reason not to start
+        pass
+
+
+def ranks_command(argv, gpus, port, script=None, python=None):
+    """The child command: the driver's own N > 1 form (one process per GPU over torch.distributed.run, rendezvous on
+    127.0.0.1) with THIS invocation's arguments.  `--n X` is rewritten to `--nbodies X` (torch.distributed.run's parser
+    finds a bare --n ambiguous)."""
+    fwd = []
+    for tok in argv:
+        fwd.append("--nbodies" if tok == "--n" else ("--nbodies=" + tok[4:]) if tok.startswith("--n=") else tok)
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(script or Path(__file__).resolve()), *fwd]
+
+
+def launch_ranks(argv, gpus, deadline_s=0.0, out=None, command=None) -> int:
+    """Start the N ranks as CHILD processes and wait for them; returns the status this process should end with.
+    * the parent never imports torch or the library: nothing here touches a GPU, and nothing is exec'ed in place;
+    * rank 0's stdout (the ONE JSON line) is relayed line by line as it arrives, stderr is inherited;
+    * SIGTERM / SIGINT received here are forwarded to the launcher child, which passes them to the ranks — rank 0 then
+      prints the safe-first line it already holds (run_sharded) — and the relay goes on until the children are gone;
+    * `deadline_s` > 0: the children's own deadlines (--deadline) are the first line of defence; if the launcher child is
+      still there 60 s later it is terminated (then killed) from here.
+    Status: the launcher child's — except that a run which relayed a bench line and was stopped by a signal ends 0 (the
+    line IS the result; the ranks that held no line died of the signal, which torch.distributed.run reports as a failure)."""
+    out = out or sys.stdout
+    cmd = command or ranks_command(argv, gpus, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL shares device buffers through dmabuf IPC on this driver stack
+    env.setdefault("OMP_NUM_THREADS", "1")                 # what torch.distributed.run would set itself (and warn about)
+    sys.stderr.write(f"[bench] --gpus {gpus} without a launcher: starting {gpus} ranks as child processes: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, env=env, preexec_fn=_die_with_parent)
+    stopped = {"by": None}
+
+    def forward(signum, _frame):
+        stopped["by"] = signum
+        try:
+            proc.send_signal(signum)
+        except (ProcessLookupError, OSError):
+            pass
+
+    previous = {}
+    try:
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            previous[sg] = signal.signal(sg, forward)
+    except ValueError:          # not the main thread (a test harness): no forwarding
+        pass
+    killer = None
+    if deadline_s and deadline_s > 0:
+        import threading
+
+        def expire():
+            sys.stderr.write(f"[bench] the ranks are still running {deadline_s + 60:.0f} s after the start: terminating them\n")
+            sys.stderr.flush()
+            forward(signal.SIGTERM, None)
+            try:
+                proc.wait(timeout=40)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+        killer = threading.Timer(deadline_s + 60.0, expire)
+        killer.daemon = True
+        killer.start()
+    lines = 0
+    try:
+        while True:
+            try:
+                text = proc.stdout.readline()
+            except InterruptedError:
+                continue
+            if not text:
+                break
+            out.write(text)
+            out.flush()
+            lines += text.lstrip().startswith("{")
+        rc = proc.wait()
+    finally:
+        if killer is not None:
+            killer.cancel()
+        for sg, h in previous.items():
+            signal.signal(sg, h)
+    if stopped["by"] is not None and lines:
+        return 0
+    return rc if rc >= 0 else 128 - rc
+
+
+def run_one_process(args) -> int:
+    """`--gpus N` in ONE process (no torch.distributed.run, or --one-process): N sharded handles, one per device, bound by the
+    library's own RCCL communicator (nb_comm_create_all) and stepped by its C loop; the same flow as a launched run
+    (run_sharded: safe-first all-gather measurement, self-checks against one unsharded handle, the N > 1 line).  No torch here."""
+    import nbodysim_amd as nb
+    from nbodysim_amd.local_ranks import LocalRanksSimulation
+
+    world, n = args.gpus, args.n
+    have = int(nb.load().nb_device_count())
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if have < world and not args.share_gpu:
+        raise SystemExit(f"--gpus {world} but this node shows {have} device(s) (--share-gpu rehearses the ranks on the devices there are)")
+    devices = [r % have for r in range(world)]
+    ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)
+    scaling = {"auto": None, "on": True, "off": False}[args.mass_scaling]
+    physics = dict(eps=EPS, precision=args.precision, rsqrt=args.rsqrt, dims=args.dims, uniform_mass=not args.general_mass, mass_scaling=scaling)
+    live = []
+
+    def make_sim(protocol, _driver):
+        sim = LocalRanksSimulation(ic, world, devices, protocol="allgather" if args.no_symmetry else protocol, tune_dt=DT,
+                                   sym_chunks_per_item=args.chunks_per_item, **physics)
+        live[:] = [sim]
+        return sim
+
+    def make_reference():
+        return nb.Simulation(ic, device=devices[0], **physics)
+
+    def device_sync():
+        for sim in live:
+            if sim.sims:
+                sim.wait()
+
+    args.backend = "rccl (one process)" if len(set(devices)) == world else "in-process exchange (shared GPU rehearsal)"
+    return run_sharded(args, ic, n, world, 0, make_sim, make_reference, device_sync, lambda: None)
 
 
 def main() -> None:
@@ -760,6 +1010,16 @@ def main() -> None:
 
     # RCCL shares device buffers between the ranks of a node through dmabuf IPC on this driver stack
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    # `python bench.py --gpus N` as typed (no launcher, N > 1).  Decided BEFORE torch, the library or any HIP call is
+    # touched: the ranks are child processes of a parent that never sees a GPU — or, without torch.distributed.run, this
+    # one process drives all N handles through the library's C loop.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_sharded:
+        if not args.one_process and torchrun_available():
+            raise SystemExit(launch_ranks(sys.argv[1:], args.gpus, args.deadline))
+        if not args.one_process:
+            sys.stderr.write("[bench] torch.distributed.run is not available: one process drives all ranks (nb_comm_create_all)\n")
+        raise SystemExit(run_one_process(args))
 
     import torch
 
@@ -770,7 +1030,7 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+            raise SystemExit("--rehearse-sharded is the ONE-rank rehearsal of the multi-rank flow: use it with --gpus 1")
         args.gpus = world
     n = args.n
     if not torch.cuda.is_available():

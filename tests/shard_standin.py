@@ -9,6 +9,9 @@ Faults are injected by name:  fault = (kind, where, rank)
                       error surfacing at wait())
            "hang"     that rank never comes back from the candidate
            "corrupt"  that rank's block drifts away from the true trajectory (a mis-ordered exchange)
+           "corrupt_late"  the same, but only from the third step on: the self-check after the warm-up (2 steps) passes,
+                      the one after the timed steps does not
+    Several faults at once: a tuple of such triples.
     where  the configuration it hits: "allgather/torch" (the safe-first one), "tune:<candidate>" (a trial of the start-up
            timing) or "final" (the tuned configuration's own run)
 """
@@ -89,14 +92,15 @@ class StandinSharded:
         self._reset()
 
     def _hit(self, kind):
-        return self.fault is not None and self.fault[0] == kind and self.fault[1] == self.where and self.fault[2] == self.plan.rank
+        faults = self.fault if (self.fault and isinstance(self.fault[0], (tuple, list))) else ([self.fault] if self.fault else [])
+        return any(f[0] == kind and f[1] == self.where and f[2] == self.plan.rank for f in faults)
 
     def _reset(self):
         st = self.nbo.state_from_flat(self.flat)
         p = self.plan
         self.m = st["m"]
         self.pos = [self.torch.from_numpy(np.stack([st["x"], st["y"]], 1).copy()) for _ in range(2)]
-        self.cur, self.pending = 0, None
+        self.cur, self.pending, self.steps_done = 0, None, 0
         self.vx, self.vy = st["vx"][p.i_begin:p.i_end].copy(), st["vy"][p.i_begin:p.i_end].copy()
 
     # -- the start-up timing: the REAL time_candidates over stand-in trials ---------------------------------------------
@@ -128,7 +132,8 @@ class StandinSharded:
             return ({"allgather": 3.0, "allreduce": 1.0}[name]) if v["ok"] else float("inf")
 
         failed = {}
-        best, job = time_candidates(names, run_one, None, 6.0, self.plan.rank, prefer=("symmetric", "allreduce", "allgather"),
+        import os
+        best, job = time_candidates(names, run_one, None, float(os.environ.get("NB_STANDIN_CANDIDATE_DEADLINE", "6.0")), self.plan.rank, prefer=("symmetric", "allreduce", "allgather"),
                                     log=lambda m: print(m, file=sys.stderr, flush=True), failed=failed)
         self.tuning = {"chosen": best, "ms_per_step": {k: (v if np.isfinite(v) else None) for k, v in job.items()}, "failed": failed}
         return best, "torch"
@@ -148,7 +153,8 @@ class StandinSharded:
             self.vx = (self.vx + ax[lo:hi] * dt32).astype(np.float32)
             self.vy = (self.vy + ay[lo:hi] * dt32).astype(np.float32)
             nxt = self.pos[self.cur ^ 1]
-            scale = np.float32(1.001) if self._hit("corrupt") else np.float32(1.0)
+            self.steps_done += 1
+            scale = np.float32(1.001) if (self._hit("corrupt") or (self._hit("corrupt_late") and self.steps_done > 2)) else np.float32(1.0)
             nxt[lo:hi, 0] = self.torch.from_numpy(((full[lo:hi, 0] + self.vx * dt32) * scale).astype(np.float32))
             nxt[lo:hi, 1] = self.torch.from_numpy(((full[lo:hi, 1] + self.vy * dt32) * scale).astype(np.float32))
             self.cur ^= 1

@@ -139,3 +139,31 @@ def test_bench_single_rank_rehearsal_of_the_node_flow_through_rccl():
     assert sf["protocol"] == "allgather" and sf["driver"] == "torch" and sf["parity_check"]["ok"] is True
     assert d["fallback"] == {"used": False} and d["phases_ms"]["rank0"]["steps"] == 4
     assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_gpus_2_as_typed_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher — the form a driver's scaling run may well use.  The
+    process starts the two ranks as children (torch.distributed.run), relays rank 0's line and returns their status.  Two ranks over
+    gloo on this one GPU (RCCL refuses two ranks per device): a rehearsal of the launch path, not a scaling measurement."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4", "--warmup", "1", "--nbodies", "32768", "--no-sustained")
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["after_timed_region"]["ok"] is True
+    assert d["fallback"] == {"used": False} and d["config"]["safe_first"]["parity_check"]["ok"] is True
+    assert d["config"]["backend"] == "gloo" and d["config"]["protocol"] in ("symmetric", "allreduce", "allgather")
+    assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_gpus_2_in_one_process_through_the_librarys_own_loop():
+    """The fallback where torch.distributed.run is missing (forced here with --one-process): ONE process, two sharded handles, no
+    torch, no process group.  On a node the handles sit on two devices and the library's RCCL loop (nb_comm_create_all / nb_comm_step)
+    runs them; on this one GPU they share the device and the library's in-process exchange stands in for the transport — same
+    kernels, same pair split, same self-check against one unsharded handle, same line."""
+    d = run_bench("--gpus", "2", "--one-process", "--share-gpu", "--steps", "4", "--warmup", "1", "--nbodies", "32768", "--no-sustained")
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong"
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["max_rel_pos"] < 1e-5 and d["parity_check"]["after_timed_region"]["steps"] == 5
+    assert d["fallback"] == {"used": False} and d["config"]["safe_first"]["parity_check"]["ok"] is True
+    assert d["config"]["safe_first"]["protocol"] == "allgather" and "in-process" in d["config"]["driver"] and "in-process" in d["config"]["backend"]
+    t = d["config"]["protocol_tuning"]
+    assert t["chosen"] == d["config"]["protocol"] and set(t["ms_per_step"]) == {"allgather", "allreduce", "symmetric"}
+    assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["energy"]["rel_drift"]) < 1e-3

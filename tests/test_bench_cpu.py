@@ -119,3 +119,72 @@ def test_unsharded_reference_steps_forward_caches_and_restarts():
     assert ref.rows(5).shape == (3, 4)
     ref.close()
     assert made[1].closed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` typed without a launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def test_the_ranks_command_is_the_drivers_own_multi_gpu_form():
+    b = load_bench()
+    assert b.torchrun_available()                                             # looked up on disk: the launching process imports no torch
+    cmd = b.ranks_command(["--gpus", "4", "--steps", "20", "--n", "65536", "--n=4096", "--warmup", "5"], 4, 29517, script="/x/bench.py", python="py")
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                   "/x/bench.py", "--gpus", "4", "--steps", "20", "--nbodies", "65536", "--nbodies=4096", "--warmup", "5"]
+    a = b.parse_args([])
+    assert a.deadline <= 420.0 and a.candidate_deadline <= 45.0 and a.one_process is False     # inside the driver's 600 s limit
+
+
+def test_launcher_relays_the_line_and_returns_the_childrens_status():
+    import io
+    b = load_bench()
+    out = io.StringIO()
+    rc = b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import sys; print('{\"value\": 1}'); sys.stderr.write('rank noise\\n')"])
+    assert rc == 0 and out.getvalue() == '{"value": 1}\n'
+    out = io.StringIO()
+    assert b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import sys; sys.exit(4)"]) == 4 and out.getvalue() == ""
+    out = io.StringIO()          # a child killed by a signal is a failure, never a silent 0
+    assert b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"]) == 128 + 9
+
+
+def test_launcher_forwards_a_stop_and_keeps_relaying_until_the_children_are_gone(tmp_path):
+    """SIGTERM at the launching process goes on to the children; what they print while stopping (rank 0: the safe-first line) is
+    still relayed, and a run that delivered a line ends 0 even though the launcher child reports the signal as a failure."""
+    import signal
+    import subprocess
+    import time
+    child = tmp_path / "child.py"
+    child.write_text("import signal, sys, time\n"
+                     "def stop(s, f):\n"
+                     "    print('{\"fallback\": {\"used\": true}}', flush=True)\n"
+                     "    sys.exit(1)\n"
+                     "signal.signal(signal.SIGTERM, stop)\n"
+                     "sys.stderr.write('child ready\\n'); sys.stderr.flush()\n"
+                     "time.sleep(60)\n")
+    code = ("import importlib.util, sys\n"
+            f"spec = importlib.util.spec_from_file_location('b', {str(ROOT / 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            f"sys.exit(b.launch_ranks([], 2, command=[sys.executable, {str(child)!r}]))\n")
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    seen = ""
+    while "child ready" not in seen and time.time() - t0 < 30:
+        seen += p.stderr.readline()
+    assert "child ready" in seen
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode == 0, err
+    assert out == '{"fallback": {"used": true}}\n'
+    assert "torch" not in code and time.time() - t0 < 30
+
+
+def test_typed_without_a_launcher_the_ranks_start_as_children_even_here():
+    """No GPU in this container: the two ranks start (torch.distributed.run, one process each), each refuses loudly — the
+    product has no CPU path — and the launcher returns their failure.  What matters here: `--gpus 2` no longer ends in
+    'must be launched with torch.distributed.run'."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "4096"],
+                       capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert "starting 2 ranks as child processes" in r.stderr and "--nproc-per-node=2" in r.stderr and "--nbodies 4096" in r.stderr
+    assert "must be launched with" not in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") == 2 and r.stdout.strip() == ""

@@ -302,6 +302,72 @@ def test_a_wrong_final_configuration_falls_back_to_the_validated_safe_line():
     assert "parity_check failed (allreduce protocol, torch loop, after the warm-up)" in errs[0]
 
 
+def test_a_safe_first_run_that_drifts_during_the_timed_steps_is_not_kept_as_the_fallback():
+    """timed_region raises only for the check after the warm-up; a failure after the K timed steps is recorded in
+    parity['ok'].  Such a safe-first line must not become the fallback.  Here the safe configuration drifts from its third step on:
+    the tuned configuration is fine, so its line is printed — and says that the safe-first measurement failed."""
+    rcs, lines, errs = _run_bench(("corrupt_late", "allgather/torch", 1))
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    assert d["fallback"] == {"used": False} and d["parity_check"]["ok"] is True
+    assert d["config"]["safe_first"]["parity_check"]["ok"] is False
+    assert "NOT kept: it left the tolerance during the timed steps" in errs[0] and "safe-first line" not in errs[0]
+
+
+def test_with_no_valid_safe_line_a_wrong_final_configuration_ends_non_zero():
+    """... and when nothing else validates either, the run ends with EXIT_PARITY on every rank instead of printing the drifted
+    safe-first line with status 0 (the pre-fix behaviour)."""
+    rcs, lines, errs = _run_bench((("corrupt_late", "allgather/torch", 1), ("corrupt", "final", 0)))
+    assert rcs == [4, 4], errs
+    assert lines == [[], []]
+    assert "NOT kept" in errs[0] and "parity_check failed (allreduce protocol, torch loop, after the warm-up)" in errs[0]
+
+
+def test_sigterm_during_a_candidate_prints_the_safe_line_and_every_rank_ends_zero():
+    """an external stop (a driver's time limit, a launcher tearing the job down) while a start-up candidate
+    is being timed — here one that hangs, with every rank's main thread inside a collective — prints the already-measured safe-first
+    line on rank 0 with fallback.used = true naming the signal; status 0 on every rank."""
+    import json
+    import signal
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, {t!r}); import shard_standin as s; "
+            "s.bench_worker({{rank}}, 2, {port}, 256, ('hang', 'tune:allreduce', 1), ())").format(t=str(TESTS), port=port)
+    env = dict(os.environ, NB_STANDIN_CANDIDATE_DEADLINE="120")          # the candidate's own deadline must not be what ends it
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(rank=r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    t0 = time.time()
+    seen = ""
+    while "[tune] rank 0: allgather:" not in seen and time.time() - t0 < 90 and procs[0].poll() is None:
+        seen += procs[0].stderr.readline()                                # the safe line is held; the first candidate is through: now inside 'allreduce'
+    assert "kept as the fallback line" in seen and "[tune] rank 0: allgather:" in seen, seen[-2000:]
+    time.sleep(1.0)
+    for p in procs:
+        p.send_signal(signal.SIGTERM)
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [e[-800:] for _, e in outs]
+    lines = [[json.loads(l) for l in out.splitlines() if l.startswith("{")] for out, _ in outs]
+    assert len(lines[0]) == 1 and lines[1] == []
+    d = lines[0][0]
+    assert d["fallback"]["used"] is True and "stopped by SIGTERM" in d["fallback"]["why"] and "creating the sharded simulation" in d["fallback"]["phase"]
+    assert d["config"]["protocol"] == "allgather" and d["parity_check"]["ok"] is True and d["value"] > 0
+    assert "stopped by SIGTERM" in outs[0][1] and "stopped by SIGTERM" in outs[1][1]
+    assert time.time() - t0 < 100
+
+
+def test_sigterm_before_anything_valid_was_measured_is_a_plain_failure():
+    """No safe line yet -> nothing to print: the rank ends with the conventional 128 + signal, never 0."""
+    import signal
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, {t!r}); import shard_standin as s; "
+            "s.bench_worker(0, 2, {port}, 256, None, ())").format(t=str(TESTS), port=port)
+    # rank 1 never starts: rank 0 waits in the first barrier of the safe-first measurement (or in forming the group)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(6.0)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode in (128 + 15, -15), (p.returncode, err[-600:])     # -15: still inside init_process_group, before run_sharded's handler
+    assert out.strip() == ""
+
+
 def test_parity_helpers_alone():
     sys.path.insert(0, str(ROOT))
     from nbodysim_amd.dist import ShardPlan, compare_with_unsharded, gather_rows, max_rel, state_rows
