@@ -205,6 +205,51 @@ def sustained_rate(advance, wait, dt, ms_per_step_hint, min_seconds=2.0, sampler
     return {"steps": done, "seconds": el, "ms_per_step": el / done * 1e3, "device_state": smp.stop()}
 
 
+def frame_costs(make, ms_per_step_hint, dt):
+    """What the reference's caller pays per FRAME through the drop-in (main.cpp:621-627: `step(); lock; copy bodies`), beside the
+    resident step rate `value` is quoted on — host buffers included, so never part of `value` (the contract: PCIe-inclusive rates
+    are noted, not reported).  `make()` -> a fresh handle of the benchmarked system.  Milliseconds per frame of
+      step            nb_step(1) + blocking nb_sync into the caller's pageable array (Simulation::step(), Simulation.hpp:67-75)
+      step_copy       the same + the caller's own copy of `bodies` (SHARED_BODIES = simulation->bodies)
+      overlapped_copy nb_snapshot_begin / _wait: frame k's transfer behind step k + 1, one frame late (Simulation::step_overlapped)
+      resident        nb_step(frames) + nb_wait: nothing leaves the device."""
+    frames = int(min(300, max(20, 400.0 / max(ms_per_step_hint, 1e-3))))
+    out = {"frames": frames}
+    with make() as g:
+        shared = g.bodies.copy()
+        g.advance(3, dt)
+        g.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            g.step(dt)
+        out["step"] = (time.perf_counter() - t0) / frames * 1e3
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            g.step(dt)
+            shared[:] = g.bodies
+        out["step_copy"] = (time.perf_counter() - t0) / frames * 1e3
+        back, inflight = g.bodies.copy(), False
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            g.advance(1, dt)
+            if inflight:
+                g.snapshot_wait()
+                shared[:] = back
+            g.snapshot_begin(back)
+            inflight = True
+        g.snapshot_wait()
+        out["overlapped_copy"] = (time.perf_counter() - t0) / frames * 1e3
+        g.wait()
+        t0 = time.perf_counter()
+        g.advance(frames, dt)
+        g.wait()
+        out["resident"] = (time.perf_counter() - t0) / frames * 1e3
+        out["bytes_per_frame"] = int(g.bodies.nbytes)
+    out["note"] = ("ms per frame of the reference caller's loop (main.cpp:621-627) through the C ABI, pageable host arrays; PCIe-inclusive, "
+                   "never part of `value`; the C++ adaptor's own figures: build/sim_thread_example frames (INTEGRATION.md §2)")
+    return out
+
+
 def kernel_instantiation(desc, precision, dims, rsqrt):
     """The exact template instantiation of the dominant force kernel as rocprofv3 prints it, from nb_describe's fields —
     what a PMC record must name to be THIS run's kernel (None for the kernels no PMC set is kept for)."""
@@ -332,9 +377,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s settled-rate measurement after the timed region")
     ap.add_argument("--no-symmetry", action="store_true", help="single GPU: the one-sided LDS-tiled kernel (north_star's design)")
     ap.add_argument("--general-mass", action="store_true", help="disable the equal-mass specialisation of the kernels")
-    ap.add_argument("--mass-scaling", default="auto", choices=["auto", "on", "off"],
-                    help="with --general-mass: fold the masses into the pair geometry — auto (the library measures at upload whether that is "
-                         "harmless for these bodies), on (NB_FLAG_MASS_SCALING), off (NB_FLAG_NO_MASS_SCALING: the 12 + 2 body)")
+    ap.add_argument("--mass-scaling", default="off", choices=["off", "on", "measured"],
+                    help="with --general-mass: fold the masses into the pair geometry — off (default: both per-pair mass multiplies, the 12 + 2 body), "
+                         "on (NB_FLAG_MASS_SCALING), measured (NB_FLAG_MASS_SCALING_MEASURED: the library measures at upload whether that is harmless "
+                         "for these bodies; unsharded handles)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
     ap.add_argument("--chunks-per-item", type=int, default=0, help="symmetric kernel: force nb_params.sym_chunks_per_item (tuning sweeps)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
@@ -469,7 +515,7 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     sharded = world > 1 or hasattr(sim, "plan")
     inner = sim.sim if sharded else sim
     secondary = secondary or {}
-    general, scaled, lds_tiled, auto = secondary.get("general"), secondary.get("scaled"), secondary.get("lds_tiled"), secondary.get("auto")
+    general, scaled, lds_tiled, auto = secondary.get("general"), secondary.get("scaled"), secondary.get("lds_tiled"), secondary.get("measured")
     elapsed, force_ms, launches = m["elapsed"], m["force_ms"], m["launches"]
     k0, u0, k1, u1 = m["energy"]
     flop_per_pair = FLOP_PER_PAIR if args.dims == 2 else 20.0   # 3-D: one more sub, fma, fma per pair side
@@ -521,7 +567,15 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
     pmc_ok = pmc is not None
     pmc = pmc or {}
     traffic_pmc = pmc.get("force_kernel_hbm_bytes_per_launch") if pmc_ok else None
-    traffic_reported = traffic_pmc if traffic_pmc else traffic           # ONE figure: `traffic`, the bandwidth and the intensity below use it
+    # `traffic` is a COUNTER figure or nothing: with no PMC record of exactly this kernel, N and plan (pmc_status != "match") it
+    # stays null and the plan-derived estimate is reported under its own name (traffic_plan) — never in the counter's place
+    traffic_reported = traffic_pmc if traffic_pmc else None
+    # the settled counterpart of `frac`: the same algorithmic flops over the mean launch duration of the >= 2 s stretch AFTER the timed
+    # region (the driver's K steps sit in the power controller's burst window: 0.880 vs 0.867 settled in round 5)
+    frac_sustained = None
+    if sustained and not sharded:
+        s_ms = sustained.get("avg_launch_ms") or sustained.get("ms_per_step")
+        frac_sustained = flop_per_pair * pairs_per_step / (s_ms * 1e-3) / 1e12 / peak if s_ms else None
     if not sharded:
         workload = (f"N={n} {args.precision} direct O(N^2), one MI355X, kernel {kernel}: "
                     + (f"symmetric pair items ({info['items']} workgroups x {info['chunks_per_item']} chunks of 64, stationary particles in "
@@ -567,6 +621,10 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
+            "frac_sustained": frac_sustained,
+            "frac_sustained_kind": ("the settled figure — quote THIS one: same flops over the mean force-launch duration of the >= 2 s of steps run after the "
+                                    "timed region (`sustained`); `frac` is the driver's K timed steps, which start before the power controller has settled"
+                                    if frac_sustained is not None else None),
             "frac_kind": "algorithmic: 14 flop x N^2 ORDERED pairs / kernel time (the contract's definition); the kernel issues fewer "
                          "flops than that because it evaluates each unordered pair once - see executed_frac",
             "mass_model": mass_note,
@@ -574,7 +632,8 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             # reference's own bodies (Simulation.hpp:565-577) do not
             "frac_equal_masses": (achieved / peak) if (um and not sharded) else None,
             "frac_individual_masses": ((achieved / peak) if (not um and not sharded) else (frac_of(general["avg_launch_ms"]) if general else None)),
-            "frac_individual_masses_default": (frac_of(auto["avg_launch_ms"]) if auto else None),
+            "frac_individual_masses_default": ((achieved / peak) if (not um and not sharded and args.mass_scaling == "off") else
+                                               (frac_of(general["avg_launch_ms"]) if general else None)),
             "executed_tflops": executed,
             "executed_frac": executed / peak if executed else None,
             "executed_flop_per_unordered_pair": ex["sym"][0 if um else 1] if symmetric else None,
@@ -586,10 +645,9 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             "kernel_instantiation": kernel_full,
             "traffic": traffic_reported,
             "traffic_source": ("PMC: profiles/hbm_traffic.json (separate rocprofv3 --pmc passes of this command on an MI355X: FETCH_SIZE x2 "
-                               "+ WRITE_SIZE per launch of the force kernel); the plan-derived figure is traffic_plan"
-                               if traffic_pmc else
-                               "work plan (no PMC file for this workload): stationary slab rows + travelling partials written once per "
-                               "launch + positions read once"),
+                               "+ WRITE_SIZE per launch of the force kernel)" if traffic_pmc else
+                               "null: no PMC record of exactly this kernel instantiation, N and work plan is kept (pmc_status); the work plan's own "
+                               "estimate is traffic_plan (stationary slab rows + travelling partials written once per launch + positions read once)"),
             "traffic_plan": traffic,
             "traffic_pmc": traffic_pmc,
             "flop_per_pair": flop_per_pair,
@@ -601,13 +659,13 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
                                       "body): untimed secondary run"}
                              if general else None),
             "general_mass_scaled": ({**scaled, "frac": frac_of(scaled["avg_launch_ms"]),
-                                     "note": "NB_FLAG_MASS_SCALING forced: masses folded into the pair geometry (11 + 2 per body); by default the library "
-                                             "takes this body only where its upload-time measurement finds the extra rounding harmless (DESIGN.md §4.1)"}
+                                     "note": "NB_FLAG_MASS_SCALING: masses folded into the pair geometry (11 + 2 per body) at the caller's request; off by "
+                                             "default (DESIGN.md §4.1: the extra rounding is data-dependent)"}
                                     if scaled else None),
-            "general_mass_default": ({**auto, "frac": frac_of(auto["avg_launch_ms"]),
-                                      "note": "individual masses with neither mass-scaling flag: the library compares the two bodies on the uploaded data "
-                                              "(two force evaluations) and folds the masses only if the accelerations agree to 2e-6 of the force scale"}
-                                     if auto else None),
+            "general_mass_measured": ({**auto, "frac": frac_of(auto["avg_launch_ms"]),
+                                       "note": "NB_FLAG_MASS_SCALING_MEASURED (opt-in): the library compares the two bodies on the uploaded data (two force "
+                                               "evaluations) and folds the masses only if the accelerations agree to 2e-6 of the force scale"}
+                                      if auto else None),
             "one_sided_lds_tiled": ({**lds_tiled, "kernel": "force_tiled" + ("3" if args.dims == 3 else "") + ("_f32" if args.precision == "fp32" else "_f64"),
                                      "frac": frac_of(lds_tiled["avg_launch_ms"]),
                                      "note": "north_star's kernel design (every ordered pair, j-tiles of 256 in LDS) on the same workload: untimed secondary run"}
@@ -617,7 +675,9 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
                     "price of evaluating every pair once with plain stores (no atomics, bit-reproducible)",
             "algorithmic_hbm_gbps": BYTES_PER_PARTICLE_STEP * n * args.steps / elapsed / 1e9,
             "kernel_hbm_gbps": (traffic_reported / (avg_launch_ms * 1e-3) / 1e9) if (traffic_reported and avg_launch_ms) else None,
-            "arithmetic_intensity_flop_per_byte": (flop_per_pair * float(n) * float(n) / traffic_reported) if traffic_reported else None,
+            "kernel_hbm_gbps_plan": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms) else None,
+            "arithmetic_intensity_flop_per_byte": flop_per_pair * float(n) / BYTES_PER_PARTICLE_STEP,       # algorithmic: 14 N flop over 36 B per particle-step
+            "arithmetic_intensity_vs_traffic": (flop_per_pair * float(n) * float(n) / (traffic_reported or traffic)) if (traffic_reported or traffic) else None,
         },
         "device_state": m["device_state"],
         "sustained": ({**sustained, "value": float(n) * float(n) * sustained["steps"] / sustained["seconds"],
@@ -983,7 +1043,7 @@ def run_one_process(args) -> int:
         raise SystemExit(f"--gpus {world} but this node shows {have} device(s) (--share-gpu rehearses the ranks on the devices there are)")
     devices = [r % have for r in range(world)]
     ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)
-    scaling = {"auto": None, "on": True, "off": False}[args.mass_scaling]
+    scaling = {"off": False, "on": True, "measured": "measured"}[args.mass_scaling]
     physics = dict(eps=EPS, precision=args.precision, rsqrt=args.rsqrt, dims=args.dims, uniform_mass=not args.general_mass, mass_scaling=scaling)
     live = []
 
@@ -1040,7 +1100,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
 
     ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)   # every rank generates the same deterministic ICs
-    scaling = {"auto": None, "on": True, "off": False}[args.mass_scaling]
+    scaling = {"off": False, "on": True, "measured": "measured"}[args.mass_scaling]
 
     rehearsal = args.rehearse_sharded and world == 1
     if world > 1 or rehearsal:
@@ -1135,15 +1195,19 @@ def main() -> None:
         if not args.general_mass:
             # the same kernel without the equal-mass specialisation (12 + 2 instead of 10 + 2 instructions per body): what a system with
             # individual masses — the reference's own bodies, Simulation.hpp:565-577 — gets
-            secondary["general"] = second(uniform_mass=False, mass_scaling=False)  # NB_FLAG_NO_MASS_SCALING: both per-pair mass multiplies (12 + 2)
-            secondary["scaled"] = second(uniform_mass=False, mass_scaling=True)    # NB_FLAG_MASS_SCALING forced: masses folded into the pair geometry (11 + 2)
-            secondary["auto"] = second(uniform_mass=False)                         # the default: the library measures at upload which of the two this data gets
+            secondary["general"] = second(uniform_mass=False)                        # the default with individual masses: both per-pair mass multiplies (12 + 2)
+            secondary["scaled"] = second(uniform_mass=False, mass_scaling=True)      # NB_FLAG_MASS_SCALING: masses folded into the pair geometry (11 + 2)
+            secondary["measured"] = second(uniform_mass=False, mass_scaling="measured")   # opt-in: the library measures at upload which of the two this data gets
         if not args.no_symmetry:
             # north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of 256 — on the same workload
             secondary["lds_tiled"] = second(steps=max(4, args.steps // 4), symmetry=False, uniform_mass=not args.general_mass)
 
     line = make_line(args, n, 1, sim, m, sustained, secondary)
     value = line["value"]
+    if not args.no_secondary and args.dims == 2:
+        line["frame_ms"] = frame_costs(lambda: nb.Simulation(ic, eps=EPS, precision=args.precision, rsqrt=args.rsqrt, device=local_rank, dims=args.dims,
+                                                             symmetry=not args.no_symmetry, uniform_mass=not args.general_mass, mass_scaling=scaling),
+                                       line["ms_per_step"], DT)
     if not args.no_cpu_baseline and args.dims == 2:
         line["cpu_baseline"] = cpu_baseline(ic, n)
         line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

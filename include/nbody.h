@@ -33,7 +33,7 @@ extern "C" {
  * nb_* symbols; tests/test_abi.py).  Test hooks live in include/nbody_debug.h and exist only in a -DNB_TEST_HOOKS build. */
 #pragma GCC visibility push(default)
 
-#define NB_ABI_VERSION 5
+#define NB_ABI_VERSION 6
 
 /* ---- particle record -------------------------------------------------------
  * Bit-compatible with the reference's `struct alignas(16) Body`
@@ -115,12 +115,18 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          ITSELF no longer cancels exactly (a spurious self-acceleration of up to 6e-8 |x| m / eps^3; total
                                          momentum is conserved to that level only) — harmless for light, similar masses, several 1e-5 of the
                                          force scale for a broad mass spectrum with close heavy pairs (tests/test_headline_gpu.py).
-                                         DEFAULT (neither this bit nor the next): the library MEASURES it at nb_create / nb_upload of an
-                                         unsharded handle — the uploaded bodies' accelerations with and without the folding, two force
-                                         evaluations — and folds only if they agree to 2e-6 of the force scale (nb_describe:
-                                         mass_scaled, mass_scaling_check).  THIS BIT: fold wherever representable (m > 0 everywhere,
-                                         m_max^(3/2) / eps^3 inside the float range), whatever the data; sharded handles fold only so */
-       NB_FLAG_NO_MASS_SCALING = 512, /* never fold: both per-pair mass multiplies stay (12 + 2 instructions per body) */
+                                         OFF BY DEFAULT (ABI 6): the same pair arithmetic on one GPU and on N, at t = 0 and later.
+                                         THIS BIT: fold wherever representable (m > 0 everywhere, m_max^(3/2) / eps^3 inside the float
+                                         range), whatever the data — the caller's decision; the ranks of a sharded run must agree on it */
+       NB_FLAG_MASS_SCALING_MEASURED = 1024, /* fold only if harmless FOR THE BODIES UPLOADED: at nb_create / nb_upload of an unsharded
+                                         handle the library evaluates their accelerations with and without the folding (two force
+                                         evaluations) and folds only if they agree to 2e-6 of the force scale, max |a| (nb_describe:
+                                         mass_scaled, mass_scaling_check).  A global figure at upload time: it does not bound the relative
+                                         error of a body whose own |a| is far below the largest, and it is not repeated as the system
+                                         evolves — the default of ABI 5, opt-in since.  The reference's own bodies (Simulation.hpp:347-603)
+                                         fail it (4e-5) and keep both multiplies.  Ignored by sharded handles (no folding) */
+       NB_FLAG_NO_MASS_SCALING = 512, /* never fold: both per-pair mass multiplies stay (12 + 2 instructions per body).  The default; the bit
+                                         overrides the two above (a host that passes a caller's flags through and must not fold) */
        /* 64 and 128 were NB_FLAG_PIPELINE / NB_FLAG_ONE_LAUNCH_STEP of ABI 4: two in-launch fusions of the step (a persistent step
           pipeline, one launch per step) that measured level or slower than two launches per step (docs/rounds/r04.md) and were removed
           in ABI 5 — nb_create rejects the bits like any unknown one */
@@ -128,6 +134,8 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          resident wave draws the next item of the list when it starts, so that the XCDs of a part, which are not
                                          equally fast, end together: -1.4 ... -2.3 % per step from 65 536 bodies up, same bits); this bit keeps
                                          item = workgroup index (A/B runs) */
+       NB_FLAG_NO_QUARTER_TAIL = 2048,/* wave-split plans of whole systems (fp32 2-D, below 49 152 bodies): keep the items of the last, partly
+                                         filled round whole instead of re-cutting them into one-chunk QUARTER items (nb_plan.h; A/B runs) */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange
@@ -151,7 +159,15 @@ typedef struct nb_params {
     void    *pos_buffers[2];/* optional caller-owned device buffers for the two full-n
                               position replicas (n * 2 * sizeof(real) bytes each, (x,y)
                               interleaved) so that a host-side collective can fill them;
-                              NULL = allocated by the library */
+                              NULL = allocated by the library.  ORDERING (this, acc_buffers and
+                              `stream`): nb_create and nb_upload write these buffers on the handle's
+                              stream, which nothing orders against the caller's other streams — so
+                              when any of the three is the caller's, both calls first wait for ALL
+                              work previously enqueued on the device (one hipDeviceSynchronize per
+                              call, never on the step path): a fill or a collective the caller
+                              queued on those buffers beforehand cannot land after the upload.
+                              Both return with the upload complete.  Between steps the ordering is
+                              the caller's, as described at nb_step_begin */
     int32_t  shard_rank;   /* this handle's rank and the number of ranks of a sharded run     */
     int32_t  shard_world;  /* (0/0 or x/1 = not sharded by the library's symmetric protocol)  */
     void    *acc_buffers[2];/* optional caller-owned device buffers of the symmetric sharded

@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libnbody_hip.so"
 
-NB_ABI_VERSION = 5
+NB_ABI_VERSION = 6
 
 # enums (include/nbody.h)
 NB_OK, NB_EINVAL, NB_ENODEVICE, NB_EHIP, NB_ENOMEM, NB_EIO, NB_EFORMAT, NB_ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -31,6 +31,8 @@ NB_SHARD_NONE, NB_SHARD_ALLGATHER, NB_SHARD_SYMMETRIC, NB_SHARD_ALLREDUCE = 0, 1
 NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SHARD_ALLREDUCE, NB_FLAG_SHARD_SINGLE, NB_FLAG_MASS_SCALING = 1, 2, 4, 8, 16, 32
 NB_FLAG_STATIC_ITEMS = 256
 NB_FLAG_NO_MASS_SCALING = 512
+NB_FLAG_MASS_SCALING_MEASURED = 1024
+NB_FLAG_NO_QUARTER_TAIL = 2048
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(

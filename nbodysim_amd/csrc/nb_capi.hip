@@ -118,6 +118,7 @@ struct nb_sim {
     uint32_t sym_ticket_base[3] = {0, 0, 0};   // what the launches so far have drawn, per launch kind (local or whole | cross | late: one counter each,
                                                // 128 bytes apart — a sharded rank's launches may run side by side)
     uint32_t sym_first_wave = 0;               // workgroups that keep their static item (the resident slots of the kernel variant); 0 = not yet known
+    bool sym_first_wave_uniform = false, sym_first_wave_scaled = false;   // the mass model of the instantiation it was asked for (do_upload resets it on a change)
     // symmetric SHARDED protocol: this rank holds the items of the tiles dealt to it
     bool sym_sharded = false;
     // symmetric REPLICATED protocol (NB_FLAG_SHARD_ALLREDUCE): the handle holds this rank's share of the pairs like a
@@ -333,6 +334,7 @@ static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t worl
     t.even_chunks = want_pairs(p, n);            // the kernel sweeps chunk pairs: even chunk counts
     t.sb = sym_tile_of(p, n);
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
+    t.quarter_tail = !(p.flags & NB_FLAG_NO_QUARTER_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
         { for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k]; t.tail_given = true; }
     return t;
@@ -418,6 +420,7 @@ static size_t host_page_size()
 constexpr size_t BOUNCE_SLOTS = 4;
 constexpr size_t BOUNCE_SLOT_BYTES = (size_t)2 << 20;       // 4 x 2 MiB: a DMA, a host memcpy and two slots of slack in flight
 constexpr size_t BOUNCE_BYTES = BOUNCE_SLOTS * BOUNCE_SLOT_BYTES;
+constexpr size_t SMALL_SYNC_BYTES = (size_t)4 << 20;      // nb_sync: below this the pack kernel writes the host staging buffer itself (no DMA)
 
 static int ensure_bounce(nb_sim *s)
 {
@@ -597,16 +600,17 @@ static void free_all(nb_sim *s)
 static int launch_force(nb_sim *s, const ForceJob &j);
 static int launch_integrate(nb_sim *s, uint32_t nslabs, double dt_kick, double dt_drift, int flags);
 
-// The automatic rule of the mass-scaled body: decided per upload FROM THE DATA, by measurement.  The
-// accelerations of the uploaded bodies are evaluated twice — with the per-pair mass multiplies (MM_GENERAL) and with the masses
-// folded into the pair geometry (MM_SCALED) — and the scaled body is taken only if the two agree to MASS_SCALING_TOL of the
-// force scale (max |a|): 2e-6, a fifth of north_star's 1e-5.  That covers everything the extra rounding depends on — the mass
-// spectrum, how close heavy pairs sit, how far from the origin the system is, the self term — without a model of any of it.
-// Equal-ish light masses pass (Plummer spheres: ~1e-7, the two bodies' ordinary rounding difference); the reference's own bodies
-// pass (Simulation.hpp:347-603: the 1e9 central mass sits AT the origin, where sigma x = 0 is exact, and dominates every
-// force); a four-decade mixture with close heavy pairs does not (6e-5: tests/test_headline_gpu.py) and keeps MM_GENERAL.
-// Cost: two force evaluations per upload (14 ms at N = 262 144).  The verdict holds for the configuration uploaded; a host
-// whose bodies will later form heavy close pairs far from the origin sets NB_FLAG_NO_MASS_SCALING.
+// The MEASURED rule of the mass-scaled body (NB_FLAG_MASS_SCALING_MEASURED; opt-in since ABI 6): decided per upload FROM THE
+// DATA.  The accelerations of the uploaded bodies are evaluated twice — with the per-pair mass multiplies (MM_GENERAL) and with
+// the masses folded into the pair geometry (MM_SCALED) — and the scaled body is taken only if the two agree to MASS_SCALING_TOL
+// of the force scale (max |a|): 2e-6, a fifth of north_star's 1e-5.  Equal-ish light masses pass (Plummer spheres at the headline
+// size: 4e-7, the two bodies' ordinary rounding difference); THE REFERENCE'S OWN BODIES DO NOT (Simulation.hpp:347-603: 4.0e-5 —
+// its light bodies sit 1e3 ... 1e5 from the origin with eps = 1, so sigma * x is rounded at that magnitude while close pairs
+// are a unit apart) and keep MM_GENERAL; a four-decade mixture with close heavy pairs fails likewise (6e-5:
+// tests/test_headline_gpu.py).  What the measure is NOT (why it is no longer the default): it is a global absolute figure at
+// t = 0 — a body whose own |a| is far below max |a| can carry a larger relative error and still pass, and a system that
+// passes at upload and later drifts from the origin or forms close heavy pairs is not measured again.
+// Cost: two force evaluations per upload (14 ms at N = 262 144).
 constexpr float MASS_SCALING_TOL = 2e-6f;
 static int choose_mass_scaling(nb_sim *s)
 {
@@ -654,8 +658,21 @@ static int choose_mass_scaling(nb_sim *s)
     return rc;
 }
 
+// Caller-owned device memory (params.pos_buffers / acc_buffers) or a caller's stream: whatever the caller enqueued on those
+// buffers before handing them over — a fill on another stream, a collective still in flight — must be THROUGH before the
+// upload writes them.  The handle's stream is non-blocking (or foreign), so nothing orders it against that work; a zero-fill
+// queued on the caller's stream could land after the upload and wipe the positions (found in round 5 by the sharded host's
+// start-up validation).  One device-wide fence per creation / upload; never on the step path.
+static int fence_foreign_work(nb_sim *s)
+{
+    if (s->own_pos && s->own_acc && s->own_stream) return NB_OK;
+    HIPCHK(hipDeviceSynchronize());
+    return NB_OK;
+}
+
 static int do_upload(nb_sim *s, const nb_body *in)
 {
+    { const int rc = fence_foreign_work(s); if (rc) return rc; }
     // Equal masses (the synthetic Plummer workload, most N-body ICs) let the force kernel hoist the
     // per-pair mass multiply: 8 instead of 9 packed ops per two pairs.  NB_FLAG_NO_UNIFORM_MASS disables it.
     s->uniform_mass = s->n > 0 && !(s->p.flags & NB_FLAG_NO_UNIFORM_MASS) && s->p.sum_order == NB_SUM_TILED;
@@ -667,13 +684,14 @@ static int do_upload(nb_sim *s, const nb_body *in)
     // sigma = m^(-1/2), sigma * (the kernels' padding coordinate 1e18) and g^3 <= (sqrt(m_max) / eps)^3 all stay finite floats
     // with room to spare; exact rsqrt only (the Quake mode keeps the reference's arithmetic).  Whether it is also HARMLESS — its
     // displacement is rounded once more, 6e-8 |x_j| / |d| per pair force, which heavy close pairs turn into several 1e-5 of the
-    // force scale — depends on the data: NB_FLAG_MASS_SCALING takes it wherever representable, NB_FLAG_NO_MASS_SCALING never, and
-    // by default choose_mass_scaling() below MEASURES it on the uploaded bodies (unsharded handles).
+    // force scale — depends on the data, so it is the CALLER's decision (ABI 6: off unless asked for — the same pair arithmetic on
+    // one GPU and on N, at t = 0 and later): NB_FLAG_MASS_SCALING takes it wherever representable, NB_FLAG_MASS_SCALING_MEASURED
+    // lets choose_mass_scaling() above measure it on the uploaded bodies (unsharded handles), NB_FLAG_NO_MASS_SCALING overrides both.
     s->mass_scaled = false;
     s->mass_scaling_dev = -1.0f;
     bool scalable = false;
     if (!s->uniform_mass && s->p.sum_order == NB_SUM_TILED && !needs_guard(s) && !s->fp64 && !s->dims3 &&
-        s->p.rsqrt_mode == NB_RSQRT_EXACT && !(s->p.flags & NB_FLAG_NO_MASS_SCALING)) {
+        s->p.rsqrt_mode == NB_RSQRT_EXACT && (s->p.flags & (NB_FLAG_MASS_SCALING | NB_FLAG_MASS_SCALING_MEASURED)) && !(s->p.flags & NB_FLAG_NO_MASS_SCALING)) {
         double mmin = HUGE_VAL, mmax = 0.0;
         bool finite = true;
         for (size_t i = 0; i < s->n; ++i) {
@@ -686,7 +704,8 @@ static int do_upload(nb_sim *s, const nb_body *in)
         scalable = finite && mmin >= 1e-30 && std::pow(mmax, 1.5) / (eps * eps * eps) <= 1e36;
     }
     const bool forced_scaling = scalable && (s->p.flags & NB_FLAG_MASS_SCALING);
-    const bool auto_scaling = scalable && !forced_scaling && s->i_count == s->n && !s->sym_sharded && !s->sym_replicated;
+    const bool auto_scaling = scalable && !forced_scaling && (s->p.flags & NB_FLAG_MASS_SCALING_MEASURED) && s->i_count == s->n && !s->sym_sharded && !s->sym_replicated;
+    const bool was_uniform = s->sym_first_wave_uniform, was_scaled = s->sym_first_wave_scaled;
     { const int rc = copy_h2d(s, s->aos_dev, in, s->n * sizeof(nb_body)); if (rc) return rc; }
     const uint32_t n = (uint32_t)s->n, g = (n + BLOCK - 1) / BLOCK;
     // both replicas get the full initial positions
@@ -716,6 +735,11 @@ static int do_upload(nb_sim *s, const nb_body *in)
     HIPCHK(hipStreamSynchronize(s->stream));  // `in` may be pageable and freed by the caller
     s->acc_valid = false;
     if (auto_scaling) { const int rc = choose_mass_scaling(s); if (rc) return rc; }
+    // the resident-slot count behind the static / dynamic item split belongs to ONE kernel instantiation (its VGPR count sets the
+    // occupancy): the check above launches MM_GENERAL whatever the verdict, and a re-upload can flip uniform_mass — ask again
+    if (auto_scaling || was_uniform != s->uniform_mass || was_scaled != s->mass_scaled) s->sym_first_wave = 0;
+    s->sym_first_wave_uniform = s->uniform_mass;
+    s->sym_first_wave_scaled = s->mass_scaled;
     return NB_OK;
 }
 
@@ -741,7 +765,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_NO_MASS_SCALING | NB_FLAG_STATIC_ITEMS)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_NO_MASS_SCALING | NB_FLAG_STATIC_ITEMS | NB_FLAG_MASS_SCALING_MEASURED | NB_FLAG_NO_QUARTER_TAIL)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||
@@ -1509,24 +1533,29 @@ extern "C" int nb_host_free(void *ptr)
 }
 
 // AoS view of the owned block into aos_dev, on the handle's stream
-static int launch_pack(nb_sim *s)
+// SoA -> 64-byte Body records of `cnt` owned particles from offset `o` of the owned block, written to `out` (device memory, or
+// page-locked host memory the device can address: the small-transfer path of nb_sync writes the staging buffer directly).
+static int launch_pack_range(nb_sim *s, BodyRec *out, uint32_t o, uint32_t cnt)
 {
-    const uint32_t ic = (uint32_t)s->i_count, g = (ic + BLOCK - 1) / BLOCK;
+    if (cnt == 0) return NB_OK;
+    const uint32_t g = (cnt + BLOCK - 1) / BLOCK, ib = (uint32_t)s->i_begin + o;
+    const size_t e = s->esz * (size_t)o;                 // vel / acc are indexed from the start of the owned block
+    const char *vel = (const char *)s->vel + e, *acc = (const char *)s->acc + e;
     if (s->dims3 && s->fp64)
-        pack_bodies3<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double4 *)s->pos[s->cur], (const double4 *)s->vel, (const double4 *)s->acc,
-                                                         s->radius, (uint32_t)s->i_begin, ic);
+        pack_bodies3<double><<<g, BLOCK, 0, s->stream>>>(out, (const double4 *)s->pos[s->cur], (const double4 *)vel, (const double4 *)acc, s->radius, ib, cnt);
     else if (s->dims3)
-        pack_bodies3<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float4 *)s->pos[s->cur], (const float4 *)s->vel, (const float4 *)s->acc,
-                                                        s->radius, (uint32_t)s->i_begin, ic);
+        pack_bodies3<float><<<g, BLOCK, 0, s->stream>>>(out, (const float4 *)s->pos[s->cur], (const float4 *)vel, (const float4 *)acc, s->radius, ib, cnt);
     else if (s->fp64)
-        pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const double2 *)s->pos[s->cur], (const double *)s->mass,
-                                                        (const double2 *)s->vel, (const double2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
+        pack_bodies<double><<<g, BLOCK, 0, s->stream>>>(out, (const double2 *)s->pos[s->cur], (const double *)s->mass,
+                                                        (const double2 *)vel, (const double2 *)acc, s->radius, ib, cnt);
     else
-        pack_bodies<float><<<g, BLOCK, 0, s->stream>>>(s->aos_dev, (const float2 *)s->pos[s->cur], (const float *)s->mass,
-                                                       (const float2 *)s->vel, (const float2 *)s->acc, s->radius, (uint32_t)s->i_begin, ic);
+        pack_bodies<float><<<g, BLOCK, 0, s->stream>>>(out, (const float2 *)s->pos[s->cur], (const float *)s->mass,
+                                                       (const float2 *)vel, (const float2 *)acc, s->radius, ib, cnt);
     HIPCHK(hipGetLastError());
     return NB_OK;
 }
+
+static int launch_pack(nb_sim *s) { return launch_pack_range(s, s->aos_dev, 0, (uint32_t)s->i_count); }
 
 extern "C" int nb_snapshot_wait(nb_sim *s)
 {
@@ -1574,6 +1603,24 @@ extern "C" int nb_sync(nb_sim *s, nb_body *out)
     const size_t bytes = s->i_count * sizeof(nb_body);
     const bool direct = pinned_covers(out, bytes);
     if (!direct && ensure_staging(s)) return NB_EHIP;
+    if (!direct && bytes <= SMALL_SYNC_BYTES) {
+        // Small systems (the reference's own 25 000 bodies = 1.6 MB per frame, main.cpp:621-627): the copy engine's start-up costs
+        // as much as the transfer.  The pack kernel writes the records STRAIGHT INTO the page-locked staging buffer over PCIe, in
+        // two halves with an event each; the host copies half 0 into the caller's (pageable) array while half 1 is on the wire.
+        // No DMA, no device-side AoS round trip.  (Measured on the reference's default start: profiles/r06_frames_*.)
+        { const int e = ensure_bounce(s); if (e) return e; }
+        const uint32_t ic = (uint32_t)s->i_count, c0 = ic < 2 * BLOCK ? ic : ((ic / 2 + BLOCK - 1) / BLOCK) * BLOCK;
+        BodyRec *stage = (BodyRec *)s->staging;
+        if ((rc = launch_pack_range(s, stage, 0, c0))) return rc;
+        HIPCHK(hipEventRecord(s->ev_bounce[0], s->stream));
+        if ((rc = launch_pack_range(s, stage + c0, c0, ic - c0))) return rc;
+        HIPCHK(hipEventRecord(s->ev_bounce[1], s->stream));
+        HIPCHK(hipEventSynchronize(s->ev_bounce[0]));
+        memcpy(out, stage, (size_t)c0 * sizeof(nb_body));
+        HIPCHK(hipEventSynchronize(s->ev_bounce[1]));
+        memcpy(out + c0, stage + c0, (size_t)(ic - c0) * sizeof(nb_body));
+        return NB_OK;
+    }
     if ((rc = launch_pack(s))) return rc;
     // registered destination: one DMA; pageable destination: staged in pieces, the host copies piece k out while
     // piece k + 1 is still in flight

@@ -68,6 +68,47 @@ int main(int argc, char **argv)
         std::printf("n=%zu frames=%d blocking=%.3f ms/frame overlapped=%.3f ms/frame differing_bodies=%zu\n", n, frames, ms[0], ms[1], diff);
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "frames") {
+        // What a maintainer who adopts the adaptor sees per frame of the reference caller's loop (main.cpp:621-627), at the
+        // reference's OWN workload by default (Simulation(): 25 000 bodies, eps = 1, dt = 0.01, clamp + boundary; Simulation.hpp:58-65)
+        // or on n Plummer bodies: ms per frame of
+        //   step_copy        step(); lock; SHARED_BODIES = bodies      (the caller's loop, blocking nb_sync)
+        //   step             step() alone                              (what the adaptor costs without the caller's own vector copy)
+        //   overlapped_copy  step_overlapped(); lock; copy             (pipelined snapshot, one frame late)
+        //   step_wait        nb_step(1) + nb_wait                      (one host round trip per step, nothing copied)
+        //   resident         advance(frames) + one sync()              (the device's own rate)
+        const bool reference = argc <= 2 || std::string(argv[2]) == "reference";
+        const size_t n = reference ? 25000 : (size_t)atol(argv[2]);
+        const int frames = argc > 3 ? atoi(argv[3]) : 200;
+        if (!reference) SIMULATION_DT.store(1e-3f);
+        const char *names[5] = {"step_copy", "step", "overlapped_copy", "step_wait", "resident"};
+        double ms[5] = {0, 0, 0, 0, 0};
+        for (int mode = 0; mode < 5; ++mode) {
+            std::unique_ptr<Simulation> sim;
+            if (reference) sim.reset(new Simulation());
+            else {
+                std::vector<Body> init(n);
+                if (nb_plummer_2d(reinterpret_cast<nb_body *>(init.data()), n, 42) != NB_OK) return 1;
+                sim.reset(new Simulation(std::move(init), 0.01f));
+            }
+            sim->advance(5);
+            sim->sync();
+            SHARED_BODIES = sim->bodies;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (mode == 4) { sim->advance(frames); sim->sync(); }
+            else for (int f = 0; f < frames; ++f) {
+                if (mode == 0 || mode == 1) sim->step();
+                else if (mode == 2) sim->step_overlapped();
+                else { sim->advance(1); if (nb_wait(sim->handle()) != NB_OK) return 1; }
+                if (mode == 0 || mode == 2) { std::lock_guard<std::mutex> lock(UPDATE_LOCK); SHARED_BODIES = sim->bodies; }
+            }
+            ms[mode] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+        }
+        std::printf("{\"workload\": \"%s\", \"n\": %zu, \"frames\": %d, \"bytes_per_frame\": %zu", reference ? "Simulation() default start" : "plummer_2d", n, frames, n * sizeof(Body));
+        for (int k = 0; k < 5; ++k) std::printf(", \"%s_ms\": %.4f", names[k], ms[k]);
+        std::printf("}\n");
+        return 0;
+    }
     const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 4096;
     std::vector<Body> init(n);
     if (nb_plummer_2d(reinterpret_cast<nb_body *>(init.data()), n, 42) != NB_OK) return 1;

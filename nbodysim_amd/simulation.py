@@ -62,17 +62,19 @@ class Simulation:
         shard_allreduce: bool = False,
         first_frame: int = 0,
         shard_single: bool = False,
-        mass_scaling: Optional[bool] = None,
+        mass_scaling=False,
         sym_chunk_pairs: int = 0,
         sym_tile: int = 0,
         pos_rows: int = 0,
         static_items: bool = False,
+        quarter_tail: bool = True,
         library=None,
     ):
         """The last arguments (from ``uniform_mass`` on) are ``nb_params.flags`` and the launch-geometry tuning fields
-        (0 / True = the library's automatic choice); the library reads no environment variables.  ``mass_scaling``: None =
-        the library measures at upload whether folding the masses into the pair geometry is harmless for these bodies
-        (include/nbody.h, NB_FLAG_MASS_SCALING), True = fold wherever representable, False = never.  ``library``: another
+        (0 / True = the library's automatic choice); the library reads no environment variables.  ``mass_scaling``: False / None
+        (default) = both per-pair mass multiplies, True = fold the masses into the pair geometry wherever representable
+        (include/nbody.h, NB_FLAG_MASS_SCALING), "measured" = the library measures at upload whether folding is harmless for
+        these bodies and folds only then (NB_FLAG_MASS_SCALING_MEASURED).  ``library``: another
         build of the library bound with ``_lib.bind`` (the tests' -DNB_TEST_HOOKS build); default the product."""
         lib = library if library is not None else L.load()
         if bodies.dtype not in (L.BODY_DTYPE, L.BODY3_DTYPE):
@@ -101,8 +103,9 @@ class Simulation:
         p.flags = ((0 if symmetry else L.NB_FLAG_NO_SYMMETRY) | (0 if uniform_mass else L.NB_FLAG_NO_UNIFORM_MASS)
                    | (0 if guided_tail else L.NB_FLAG_NO_GUIDED_TAIL) | (L.NB_FLAG_SHARD_ALLREDUCE if shard_allreduce else 0)
                    | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0)
-                   | (0 if mass_scaling is None else L.NB_FLAG_MASS_SCALING if mass_scaling else L.NB_FLAG_NO_MASS_SCALING)
-                   | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
+                   | (L.NB_FLAG_MASS_SCALING_MEASURED if mass_scaling == "measured" else L.NB_FLAG_MASS_SCALING if mass_scaling is True
+                      else L.NB_FLAG_NO_MASS_SCALING if mass_scaling is False else 0)
+                   | (L.NB_FLAG_STATIC_ITEMS if static_items else 0) | (0 if quarter_tail else L.NB_FLAG_NO_QUARTER_TAIL))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail

@@ -39,10 +39,19 @@ def test_bench_line_contract():
     assert rf["kernel"] == "force_sym_f32" and rf["kernel"] in d["config"]["workload"] and "LDS tile" not in d["config"]["workload"]
     assert 0 < rf["executed_frac"] < rf["frac"] and abs(rf["executed_frac"] - rf["executed_tflops"] / rf["peak"]) < 1e-9
     assert abs(rf["executed_frac"] / rf["frac"] - 17.0 / 28.0) < 0.04             # 17 flop per unordered pair vs 2 x 14 algorithmic (+ the one-sided diagonal items)
-    assert rf["traffic"] > 36 * 32768 and rf["traffic_pmc"] is None and rf["traffic"] == rf["traffic_plan"]   # no PMC record is kept for N = 32 768
+    # no PMC record is kept for N = 32 768: the counter fields stay NULL (never plan-derived); the plan's estimate has its own name
+    assert rf["traffic"] is None and rf["traffic_pmc"] is None and rf["traffic_plan"] > 36 * 32768 and rf["kernel_hbm_gbps"] is None and rf["kernel_hbm_gbps_plan"] > 0
+    # the settled fraction next to the burst one: from the force launches of the >= 2 s stretch after the timed region
+    assert 0 < rf["frac_sustained"] < 1.2 and "settled" in rf["frac_sustained_kind"]
+    assert abs(rf["frac_sustained"] - 14.0 * 32768.0 ** 2 / (d["sustained"]["avg_launch_ms"] * 1e-3) / 1e12 / 157.3) < 1e-9
     # PMC provenance: the line names the exact instantiation that ran; counter figures appear only with a record of exactly it
     assert rf["kernel_instantiation"] == "nbk::force_sym_f32<0, 0, false, true>" and rf["pmc_status"] == "none" and rf["pmc_commit"] is None
-    assert rf["valu_busy"] is None and abs(rf["arithmetic_intensity_flop_per_byte"] - 14.0 * 32768.0 ** 2 / rf["traffic"]) < 1e-6 * rf["arithmetic_intensity_flop_per_byte"]
+    assert rf["valu_busy"] is None and abs(rf["arithmetic_intensity_flop_per_byte"] - 14.0 * 32768.0 / 36.0) < 1e-6
+    assert abs(rf["arithmetic_intensity_vs_traffic"] - 14.0 * 32768.0 ** 2 / rf["traffic_plan"]) < 1e-6 * rf["arithmetic_intensity_vs_traffic"]
+    # what the reference's caller pays per frame through the drop-in: PCIe-inclusive, beside `value`, never in it
+    fm = d["frame_ms"]
+    assert {"step", "step_copy", "overlapped_copy", "resident", "frames", "bytes_per_frame"} <= set(fm) and fm["bytes_per_frame"] == 64 * 32768
+    assert all(fm[k] > 0 for k in ("step", "step_copy", "overlapped_copy", "resident"))
     g = rf["general_mass"]
     # individual masses: 12 + 2 ops per body instead of 10 + 2.  WHICH kernel ran is asserted (its template instantiation: MM_GENERAL = 1,
     # mass-scaled = 2), never how long it took: durations are recorded fields; their ordering is a `-m perf` matter (tests/test_perf_order.py)
@@ -65,14 +74,15 @@ def test_bench_line_contract():
     sc = rf["general_mass_scaled"]
     assert sc["mass_scaled"] is True and g["mass_scaled"] is False and sc["avg_launch_ms"] > 0
     assert sc["kernel_instantiation"] == "nbk::force_sym_f32<0, 2, false, true>"
-    # the default with individual masses: MEASURED at upload (scaled vs unscaled accelerations of these bodies, 2e-6 of the force scale).
-    # At the headline size the light equal masses pass (4e-7: tests/test_headline_gpu.py); at this small N with eps = 0.01 the closest
-    # pairs dominate a body's force and the verdict may go either way — what is asserted is that the kernel that ran follows the figure
-    au = rf["general_mass_default"]
+    # folding is the caller's decision since ABI 6: the default with individual masses is the 12 + 2 body; the MEASURED rule is opt-in
+    # (scaled vs unscaled accelerations of these bodies, 2e-6 of the force scale).  At the headline size the light equal masses pass
+    # (4e-7: tests/test_headline_gpu.py); at this small N with eps = 0.01 the closest pairs dominate a body's force and the verdict may
+    # go either way — what is asserted is that the kernel that ran follows the figure
+    au = rf["general_mass_measured"]
     assert au["mass_scaling_check"] is not None and au["mass_scaling_check"] >= 0
     assert au["mass_scaled"] is (au["mass_scaling_check"] <= 2e-6)
     assert au["kernel_instantiation"] == (sc if au["mass_scaled"] else g)["kernel_instantiation"]
-    assert g["mass_scaling_check"] is None and abs(rf["frac_individual_masses_default"] - au["frac"]) < 1e-12
+    assert g["mass_scaling_check"] is None and abs(rf["frac_individual_masses_default"] - g["frac"]) < 1e-12
     if d["device_state"]:                       # hwmon files readable on this box
         assert {"at_start", "at_end", "sclk_mhz_mean", "power_w_mean"} <= set(d["device_state"])
 

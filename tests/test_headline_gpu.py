@@ -81,18 +81,19 @@ def test_headline_kernel_accelerations_and_two_steps_vs_fp64_direct(headline_ic,
     assert np.max(np.abs(one["acc"].astype(np.float64) - np.stack([st1["ax"], st1["ay"]], 1))) < 2e-5 * scale
 
 
-@pytest.mark.parametrize("mass_scaling", [True, False, None])
+@pytest.mark.parametrize("mass_scaling", [True, False, "measured"])
 def test_headline_kernel_general_masses_vs_fp64_direct(headline_ic, oracle_step1, nbo, mass_scaling):
-    """The same plan without the equal-mass specialisation (12 + 2 ops per body), with NB_FLAG_MASS_SCALING (masses folded
-    into the pair geometry, 11 + 2), and with neither flag (None: the library measures at upload): all against the fp64
-    direct sum of EVERY particle.  With the equal, small masses of this workload the extra rounding of the scaled form
-    does not show — and the upload-time measurement says so (mass_scaling_check ~1e-7 -> the scaled body is taken)."""
+    """The same plan without the equal-mass specialisation (12 + 2 ops per body: the default with individual masses), with
+    NB_FLAG_MASS_SCALING (masses folded into the pair geometry, 11 + 2), and with NB_FLAG_MASS_SCALING_MEASURED (the library
+    measures at upload): all against the fp64 direct sum of EVERY particle.  With the equal, small masses of this workload the
+    extra rounding of the scaled form does not show — and the upload-time measurement says so (mass_scaling_check ~1e-7 -> the
+    scaled body is taken)."""
     ic = headline_ic
     with nb.Simulation(ic, eps=EPS, uniform_mass=False, mass_scaling=mass_scaling) as sim:
         d = sim.describe()
         assert "symmetric=1" in d and "uniform_mass=0" in d and f"mass_scaled={int(mass_scaling is not False)}" in d, d
         check = float(d.split("mass_scaling_check=")[1].split()[0])
-        assert (0 <= check < 2e-6) if mass_scaling is None else check == -1.0, d          # measured only where the library decides
+        assert (0 <= check < 2e-6) if mass_scaling == "measured" else check == -1.0, d          # measured only where the caller asked for it
         assert np.array_equal(sim.sync()["acc"], ic["acc"])                                   # the check leaves the uploaded acc field alone
         acc = sim.accelerations().astype(np.float64)
     ref = np.stack([oracle_step1["ax"], oracle_step1["ay"]], 1)          # the oracle's accelerations at x_0, EVERY particle
@@ -123,18 +124,20 @@ def test_mass_mixture_scaled_kernel_vs_fp64_and_fallbacks(nbo):
     errs = {}
     checks = {}
     for name, kw in (("default", {}), ("scaled", dict(mass_scaling=True)), ("one-sided", dict(symmetry=False)),
-                     ("one-sided scaled", dict(symmetry=False, mass_scaling=True)), ("unscaled", dict(mass_scaling=False))):
+                     ("one-sided scaled", dict(symmetry=False, mass_scaling=True)), ("measured", dict(mass_scaling="measured")),
+                     ("one-sided measured", dict(symmetry=False, mass_scaling="measured"))):
         with nb.Simulation(ic, eps=EPS, **kw) as sim:
-            # THE AUTOMATIC RULE (no flag: "default", "one-sided"): the library measured the two bodies against each other on these
-            # bodies at upload, found them several 1e-5 of the force scale apart, and kept the per-pair multiplies
-            assert f"mass_scaled={int('scaled' in name and name != 'unscaled')}" in sim.describe() and "uniform_mass=0" in sim.describe()
+            # THE MEASURED RULE (NB_FLAG_MASS_SCALING_MEASURED): the library measured the two bodies against each other on these
+            # bodies at upload, found them several 1e-5 of the force scale apart, and kept the per-pair multiplies.  With no flag
+            # (ABI 6) nothing is measured and nothing is folded
+            assert f"mass_scaled={int(name.endswith('scaled'))}" in sim.describe() and "uniform_mass=0" in sim.describe()
             checks[name] = float(sim.describe().split("mass_scaling_check=")[1].split()[0])
             acc = sim.accelerations().astype(np.float64)
         errs[name] = float(np.max(np.abs(acc - ref)) / scale)
-    assert checks["default"] > 2e-6 and checks["one-sided"] > 2e-6 and checks["scaled"] == checks["unscaled"] == -1.0, checks
-    assert errs["unscaled"] == errs["default"]                          # the rule's fallback IS the 12 + 2 body
+    assert checks["measured"] > 2e-6 and checks["one-sided measured"] > 2e-6 and checks["scaled"] == checks["default"] == checks["one-sided"] == -1.0, checks
+    assert errs["measured"] == errs["default"] and errs["one-sided measured"] == errs["one-sided"]      # the rule's fallback IS the 12 + 2 body
     print("mass mixture, max error / force scale: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items())
-          + f"; upload-time check (scaled vs unscaled, of the force scale): symmetric {checks['default']:.2e}, one-sided {checks['one-sided']:.2e}")
+          + f"; upload-time check (scaled vs unscaled, of the force scale): symmetric {checks['measured']:.2e}, one-sided {checks['one-sided measured']:.2e}")
     assert errs["default"] < 2e-5 and errs["one-sided"] < 2e-5, errs
     assert errs["scaled"] < 2e-4 and errs["one-sided scaled"] < 2e-4, errs
     # the mass-scaled form's SELF TERM (include/nbody.h): a body's pair with itself leaves up to 6e-8 |x| m / eps^3 behind, so the

@@ -272,3 +272,71 @@ def test_handles_and_communicators_release_their_device_memory():
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20, f"device memory lost over 8 cycles: {(free0 - free1) / 2**20:.1f} MiB"
+
+
+def test_caller_owned_buffers_filled_on_another_stream_right_before_nb_create():
+    """VERDICT r5 next-round 3 — the round-5 stream race, pinned at the C boundary.  A plain host hands nb_create its own position
+    replicas (nb_params.pos_buffers) and zero-fills them on ITS stream just before: the handle's stream is non-blocking, so nothing
+    orders the library's upload against that fill, and a fill still queued could land AFTER the upload and wipe the positions.
+    nb_create / nb_upload therefore wait for all previously enqueued device work when a buffer or the stream is the caller's
+    (include/nbody.h, nb_params.pos_buffers).  Here the fill sits behind ~30 ms of queued memsets on a second non-blocking stream,
+    so without the fence the upload would finish long before it.  Run once — the ordering is by construction, not by luck."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    n = 65536
+    ic = nb.plummer_2d(n, 9)
+    nb.load()
+    stream, scratch = C.c_void_p(), C.c_void_p()
+    bufs = [C.c_void_p(), C.c_void_p()]
+    big = 2 << 30
+    assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0                # hipStreamNonBlocking
+    assert hip.hipMalloc(C.byref(scratch), big) == 0
+    for b in bufs:
+        assert hip.hipMalloc(C.byref(b), n * 8) == 0
+
+    def queue_fill():
+        for _ in range(16):                                                     # tens of milliseconds of work ahead of the fill
+            assert hip.hipMemsetAsync(scratch, 0, big, stream) == 0
+        for b in bufs:
+            assert hip.hipMemsetAsync(b, 0, n * 8, stream) == 0                 # the host's "initialise my buffers", still queued ...
+
+    def device_rows(b):
+        out = np.empty((n, 2), np.float32)
+        assert hip.hipMemcpy(out.ctypes.data, b, n * 8, 2) == 0                 # hipMemcpyDeviceToHost (blocking: after everything)
+        return out
+    try:
+        queue_fill()
+        with nb.Simulation(ic, eps=0.05, pos_buffers=(bufs[0].value, bufs[1].value)) as sim:        # ... when nb_create uploads
+            assert sim.pos_buffer(0) in (bufs[0].value, bufs[1].value)
+            assert hip.hipStreamSynchronize(stream) == 0
+            for b in bufs:
+                assert np.array_equal(bits(device_rows(b)), bits(ic["pos"])), "the caller's queued fill landed after the upload"
+            got = sim.sync()
+            assert np.array_equal(bits(got["pos"]), bits(ic["pos"])) and np.array_equal(bits(got["vel"]), bits(ic["vel"]))
+            # the same hazard at nb_upload
+            moved = ic.copy()
+            moved["pos"] += np.float32(0.25)
+            queue_fill()
+            sim.upload(moved)
+            assert hip.hipStreamSynchronize(stream) == 0
+            for b in bufs:
+                assert np.array_equal(bits(device_rows(b)), bits(moved["pos"]))
+            # and the handle computes with what was uploaded: against a library-owned handle of the same bodies, bit for bit
+            sim.advance(2, 1e-3)
+            mine = sim.sync().copy()
+        with nb.Simulation(moved, eps=0.05) as ref:
+            ref.advance(2, 1e-3)
+            want = ref.sync()
+        for f in ("pos", "vel", "acc"):
+            assert np.array_equal(bits(mine[f]), bits(want[f])), f
+    finally:
+        hip.hipStreamSynchronize(stream)
+        for b in bufs + [scratch]:
+            hip.hipFree(b)
+        hip.hipStreamDestroy(stream)

@@ -698,17 +698,17 @@ def test_reference_full_default_start_through_the_gpu_path(nbo):
     assert max_rel(one[far, 0:2], want1[far, 0:2]) < 1e-6 and max_rel(one[far, 2:4], want1[far, 2:4]) < 1e-6
     assert max_rel(five[:, 0:2], want5[:, 0:2]) < 1e-6 and max_rel(five[1:, 2:4], want5[1:, 2:4]) < 1e-5
     assert (np.hypot(five[:, 2], five[:, 3]) <= 1000.0 * (1 + 1e-6)).all()              # the clamp held
-    # fast mode: symmetric kernel with individual masses against the exact-rsqrt restatement — as the library chooses, with the
-    # per-pair multiplies forced, and with the masses folded into the pair geometry forced.  The library's own choice here is NOT
-    # to fold: its upload-time measurement finds the folded body 4e-5 of the force scale away on these bodies (light bodies sit
-    # 1e3 ... 1e5 from the origin with eps = 1: sigma x is rounded at that magnitude while their close pairs are a unit apart)
+    # fast mode: symmetric kernel with individual masses against the exact-rsqrt restatement — by default (both per-pair multiplies),
+    # with the library's upload-time measurement asked for, and with the masses folded into the pair geometry by force.  The
+    # measurement's verdict here is NOT to fold: it finds the folded body 4e-5 of the force scale away on these bodies (light bodies
+    # sit 1e3 ... 1e5 from the origin with eps = 1: sigma x is rounded at that magnitude while their close pairs are a unit apart)
     ex = nbo.state_to_flat(nbo.step_f32(nbo.state_from_flat(flat), 1.0, 0.01, 5, nbo.RSQRT_EXACT, 3))
-    for scaling in (None, False, True):
+    for scaling in ("measured", False, True):
         with nb.Simulation(ic, eps=1.0, extras=3, mass_scaling=scaling) as sim:
             d = sim.describe()
             assert "symmetric=1" in d and "uniform_mass=0" in d
             check = float(d.split("mass_scaling_check=")[1].split()[0])
-            assert ("mass_scaled=0" in d and check > 2e-6) if scaling is None else (f"mass_scaled={int(scaling)}" in d and check == -1.0), d
+            assert ("mass_scaled=0" in d and check > 2e-6) if scaling == "measured" else (f"mass_scaled={int(scaling)}" in d and check == -1.0), d
             sim.advance(5, 0.01)
             fast = flat_from_bodies(sim.sync())
         if scaling is not True:             # the folded body is what the measurement refused: it is only required to run
