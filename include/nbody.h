@@ -134,8 +134,6 @@ enum { NB_FLAG_NO_SYMMETRY     = 1,   /* one-sided kernels only (every ordered p
                                          resident wave draws the next item of the list when it starts, so that the XCDs of a part, which are not
                                          equally fast, end together: -1.4 ... -2.3 % per step from 65 536 bodies up, same bits); this bit keeps
                                          item = workgroup index (A/B runs) */
-       NB_FLAG_NO_QUARTER_TAIL = 2048,/* wave-split plans of whole systems (fp32 2-D, below 49 152 bodies): keep the items of the last, partly
-                                         filled round whole instead of re-cutting them into one-chunk QUARTER items (nb_plan.h; A/B runs) */
        NB_FLAG_SHARD_SINGLE    = 16 };/* shard_world = 1, i_count = n: run the sharded symmetric protocol (or, with
                                          NB_FLAG_SHARD_ALLREDUCE, the replicated one) with ONE rank — every pair is "local",
                                          the reduce-scatter / all-gather degenerate to copies.  For rehearsing the exchange

@@ -32,7 +32,6 @@ NB_FLAG_NO_SYMMETRY, NB_FLAG_NO_UNIFORM_MASS, NB_FLAG_NO_GUIDED_TAIL, NB_FLAG_SH
 NB_FLAG_STATIC_ITEMS = 256
 NB_FLAG_NO_MASS_SCALING = 512
 NB_FLAG_MASS_SCALING_MEASURED = 1024
-NB_FLAG_NO_QUARTER_TAIL = 2048
 
 #: numpy view of the reference's 64-byte ``Body`` record (Body.hpp:6-13, Vec2.hpp:17-20)
 BODY_DTYPE = np.dtype(

@@ -334,7 +334,6 @@ static SymTuning tuning_of(const nb_params &p, bool fp64, int cus, uint32_t worl
     t.even_chunks = want_pairs(p, n);            // the kernel sweeps chunk pairs: even chunk counts
     t.sb = sym_tile_of(p, n);
     t.guided_tail = !(p.flags & NB_FLAG_NO_GUIDED_TAIL);
-    t.quarter_tail = !(p.flags & NB_FLAG_NO_QUARTER_TAIL);
     if (p.sym_tail[0] > 0.0f || p.sym_tail[1] > 0.0f || p.sym_tail[2] > 0.0f)
         { for (int k = 0; k < 3; ++k) t.tail_at[k] = (double)p.sym_tail[k]; t.tail_given = true; }
     return t;
@@ -765,7 +764,7 @@ extern "C" nb_sim *nb_create(const nb_body *init, size_t n, const nb_params *par
         nb_set_error("nb_create: quake rsqrt / sequential order are fp32 (reference arithmetic) modes");
         return nullptr;
     }
-    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_NO_MASS_SCALING | NB_FLAG_STATIC_ITEMS | NB_FLAG_MASS_SCALING_MEASURED | NB_FLAG_NO_QUARTER_TAIL)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
+    if (p.flags & ~(NB_FLAG_NO_SYMMETRY | NB_FLAG_NO_UNIFORM_MASS | NB_FLAG_NO_GUIDED_TAIL | NB_FLAG_SHARD_ALLREDUCE | NB_FLAG_SHARD_SINGLE | NB_FLAG_MASS_SCALING | NB_FLAG_NO_MASS_SCALING | NB_FLAG_STATIC_ITEMS | NB_FLAG_MASS_SCALING_MEASURED)) { nb_set_error("nb_create: unknown bits in flags 0x%x", (unsigned)p.flags); return nullptr; }
     if (p.extras & ~(NB_EXTRA_VCLAMP | NB_EXTRA_BOUNDARY)) { nb_set_error("nb_create: unknown bits in extras 0x%x", (unsigned)p.extras); return nullptr; }
     if (p.sym_chunks_per_item < 0 || p.sym_aux_stream < -1 || p.sym_aux_stream > 1 || p.j_slices < 0 || p.sym_chunk_pairs < -1 || p.sym_chunk_pairs > 1 ||
         (p.sym_tile != 0 && p.sym_tile != (int32_t)SYM_SB_WS && p.sym_tile != (int32_t)SYM_SB) ||

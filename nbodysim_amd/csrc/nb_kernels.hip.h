@@ -483,14 +483,12 @@ enum { MM_UNIFORM = 0, MM_GENERAL = 1, MM_SCALED = 2 };
 // WS (wave split, force_sym_f32<..., WS = true>): the 4 waves of the workgroup hold the SAME stationary particles and
 // take the item's chunks in turn (wave w: chunks w, w + 4, ...), so a travelling partial is complete inside ONE wave
 // and is stored straight from the registers: no LDS combine, no barrier per chunk.
-// NP = packed stationary pairs per lane: SYM_P everywhere but in the QUARTER items of a wave-split plan (NP = 1, classic combine:
-// the 4 waves hold different quarters of the tile's 512 particles and sweep the same chunks; force_sym_f32_body).
-template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false, int NP = SYM_P>
+template <int RSQ, int MM, bool DIAG, bool WS = false, bool WT = false>
 __device__ __forceinline__
 void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, const float *__restrict__ sigma,
                 float2 *__restrict__ slab_r_row, uint32_t n, uint32_t c0, uint32_t cnt,
-                const v2f (&xi)[NP], const v2f (&yi)[NP], const v2f (&mi)[NP],
-                v2f (&ax)[NP], v2f (&ay)[NP], float eps2, float um_mass, float2 (*red)[4][64])
+                const v2f (&xi)[SYM_P], const v2f (&yi)[SYM_P], const v2f (&mi)[SYM_P],
+                v2f (&ax)[SYM_P], v2f (&ay)[SYM_P], float eps2, float um_mass, float2 (*red)[4][64])
 {
     constexpr bool UM = MM == MM_UNIFORM, MS = MM == MM_SCALED;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
@@ -525,7 +523,7 @@ void sym_chunks(const float2 *__restrict__ pos, const float *__restrict__ mass, 
             if constexpr (MS) er = lane_rot(eq, addr);
             const v2f xj = {xq, xq}, yj = {yq, yq};
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
+            for (int p = 0; p < SYM_P; ++p) {
                 v2f dx, dy, r2;
                 if constexpr (MS) {
                     const v2f ns = {mq, mq};                               // -sigma_j
@@ -771,23 +769,6 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
     }
     NB_STAMP(1);                                                  // (tools/sym_timeline.hip only; empty in the product)
     float2 *__restrict__ rrow = slab_r + it.r_base;               // rrow[j] = travelling partial of particle j
-    if constexpr (WS && !PAIRS) {
-        // QUARTER item (nb_plan.h, SYM_ITEM_QUARTER; uniform over the workgroup): wave w keeps only register pair p = w — the 128
-        // particles it would finish and store anyway — and all 4 waves sweep the SAME chunk(s): the classic form's sweep with one
-        // packed pair per lane, travelling partials combined over the waves through LDS.  The stationary sums need no combine.
-        if (it.group & SYM_ITEM_QUARTER) {
-            v2f x1[1], y1[1], m1[1], a1x[1] = {(v2f){0.f, 0.f}}, a1y[1] = {(v2f){0.f, 0.f}};
-            x1[0] = w == 0 ? xi[0] : w == 1 ? xi[1] : w == 2 ? xi[2] : xi[3];
-            y1[0] = w == 0 ? yi[0] : w == 1 ? yi[1] : w == 2 ? yi[2] : yi[3];
-            m1[0] = w == 0 ? mi[0] : w == 1 ? mi[1] : w == 2 ? mi[2] : mi[3];
-            if (diag) sym_chunks<RSQ, MM, true, false, WT, 1>(pos, mass, sigma, rrow, n, it.c0, it.cnt, x1, y1, m1, a1x, a1y, eps2, um_mass, red);
-            else      sym_chunks<RSQ, MM, false, false, WT, 1>(pos, mass, sigma, rrow, n, it.c0, it.cnt, x1, y1, m1, a1x, a1y, eps2, um_mass, red);
-            float4 a = make_float4(a1x[0].x, a1y[0].x, a1x[0].y, a1y[0].y);
-            if constexpr (UM) { a.x *= um_mass; a.y *= um_mass; a.z *= um_mass; a.w *= um_mass; }
-            store16<WT>(reinterpret_cast<float4 *>(&(slab_s + (size_t)s_row * SB)[w * 128u + 2u * lane]), a);
-            return;
-        }
-    }
     if constexpr (PAIRS) {
         if (diag) sym_chunks2<RSQ, MM, true, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);
         else      sym_chunks2<RSQ, MM, false, WS, WT>(pos, mass, rrow, n, it.c0, it.cnt, xi, yi, mi, ax, ay, eps2, um_mass, red2);

@@ -224,31 +224,6 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         guided(local_items, local_rows_of);
         guided(cross_items, cross_rows_of);
     }
-    // Quarter tail (round 6).  A wave-split plan without a guided tail is `items` workgroups of one chunk per wave: items / CUs
-    // full rounds and one partly filled round at the end (2 450 items = 9.57 rounds at N = 25 000 on 256 CUs: the launch lasts 10,
-    // DESIGN.md §4.1).  The quantum cannot be cut along the chunks (one chunk per wave already), but it can along the STATIONARY
-    // side: the items of that last round — the last `items mod CUs` of the list, which is the order workgroups start in — are
-    // re-cut into one item per chunk whose 4 waves take 128 stationary particles each (SYM_ITEM_QUARTER): four times as many
-    // workgroups, each a quarter as long, so the last round fills the chip several waves deep instead of one wave per SIMD.
-    // Same slab layout (one stationary row per item, the travelling segment of the tile unchanged).  Only with at least two full
-    // rounds before it (the measured regime); chunk-pair plans keep their items (a quarter item sweeps single chunks).
-    if (no_tail && tune.quarter_tail && !tune.even_chunks && world == 1 && g.sb == SYM_SB_WS) {
-        const size_t total = local_items.size(), rem = total % cus;
-        if (total >= 2ull * cus && rem > 0) {
-            std::vector<SymItem> out(local_items.begin(), local_items.end() - (std::ptrdiff_t)rem);
-            for (size_t k = total - rem; k < total; ++k) {
-                const SymItem &it = local_items[k];
-                --local_rows_of[it.tile];
-                for (uint32_t c = 0; c < it.cnt; ++c) {
-                    SymItem q = it;
-                    q.c0 = it.c0 + c; q.cnt = 1u; q.group = SYM_ITEM_QUARTER;
-                    out.push_back(q);
-                    ++local_rows_of[it.tile];
-                }
-            }
-            local_items.swap(out);
-        }
-    }
     // Slab layout.  Stationary rows: a tile's rows are contiguous (local, cross, then late items).
     // Travelling partials: one segment per (tile, group) holding exactly the particle range the group's
     // symmetric items of that tile cover (contiguous by construction: items of a tile in one list are
@@ -292,7 +267,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         if (thi[I] > tlo[I]) add_seg(I, tlo[I], thi[I], 2u, base_late);
     pl.slab_r_elems = off;
     pl.units_local = pl.units_cross = pl.units_late = 0;
-    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_base = base_local[it.tile]; it.group = 0u | (it.group & SYM_ITEM_QUARTER); pl.units_local += it.cnt; }
+    for (auto &it : local_items) { it.s_row = next_local[it.tile]++; it.r_base = base_local[it.tile]; it.group = 0u; pl.units_local += it.cnt; }
     for (auto &it : cross_items) { it.s_row = next_cross[it.tile]++; it.r_base = base_cross[it.tile]; it.group = 1u; pl.units_cross += it.cnt; }
     for (auto &it : late_items)  { it.s_row = next_late[it.tile]++;  it.r_base = base_late[it.tile];  it.group = 2u; pl.units_late += it.cnt; }
     pl.n_local = (uint32_t)local_items.size();

@@ -26,11 +26,7 @@ constexpr uint32_t SYM_CH = 64;     // travelling chunk (one particle per lane o
 //            slab_r[r_base + j] (the item's segment starts at particle seg.lo: r_base = seg.off - seg.lo,
 //            which can be negative)
 //   diag     1 = the chunks are the tile's own particles (one-sided, no travelling output)
-//   group    0 local (pairs inside the rank's block), 1 cross-block, 2 late (held-back local); + SYM_ITEM_QUARTER for a
-//            QUARTER item of a wave-split plan: the 4 waves share out the tile's 512 STATIONARY particles (128 each) and all
-//            sweep the item's chunk(s) — a quarter of the wave x chunk quantum of an ordinary wave-split item, same slab row,
-//            same travelling partials (combined over the waves through LDS); the fine-grained filler of a launch's last round
-constexpr uint32_t SYM_ITEM_QUARTER = 0x100u;
+//   group    0 local (pairs inside the rank's block), 1 cross-block, 2 late (held-back local)
 struct SymItem { uint32_t tile, c0, cnt, s_row; int64_t r_base; uint32_t diag, group; };
 static_assert(sizeof(SymItem) == 32, "SymItem is read by the kernels as 32 bytes");
 
@@ -49,8 +45,6 @@ struct SymTuning {
     uint32_t late_units = 0;      // chunk-units of local work held back for the side stream (sharded ranks)
     uint32_t late_chunks = 2;     // chunks per late item
     bool guided_tail = true;      // finer items at the end of each launch
-    bool quarter_tail = true;     // wave-split plans without a guided tail (whole systems below SYM_WS_MAX_N): the items of the last,
-                                  // partly filled round (items mod CUs) are re-cut into one-chunk QUARTER items (SYM_ITEM_QUARTER)
     bool even_chunks = false;     // cut items into EVEN chunk counts: the fp32 2-D kernel sweeps chunk PAIRS (sym_chunks2), and
                                   // an odd item wastes half a pair
     uint32_t sb = SYM_SB;         // particles per block-tile: SYM_SB, or SYM_SB_WS for the wave-split kernels, whose items are

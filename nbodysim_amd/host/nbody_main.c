@@ -14,7 +14,6 @@
  *              [-no-symmetry] one-sided kernels / all-gather protocol (nb_params.flags)
  *              [-mass-scaling | -mass-scaling-measured | -no-mass-scaling]  individual masses: fold them into the pair geometry wherever
  *                                                  representable / only if the library's upload-time measurement finds it harmless / never (default)
- *                            (default: the library measures at upload whether folding is harmless for these bodies)
  *              [-allreduce]  with -shards: the replicated protocol (every handle integrates all n; in-process all-reduce)
  *              [-late-us US] sharded symmetric protocol: local work held back for the side stream (nb_params.sym_late_us)
  *              [-rccl]       with -shards P: exchange through RCCL instead (nb_comm_create_all + nb_comm_step: collectives on a
@@ -106,7 +105,6 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-mass-scaling")) p.flags |= NB_FLAG_MASS_SCALING;
         else if (!strcmp(argv[i], "-mass-scaling-measured")) p.flags |= NB_FLAG_MASS_SCALING_MEASURED;
         else if (!strcmp(argv[i], "-no-mass-scaling")) p.flags |= NB_FLAG_NO_MASS_SCALING;
-        else if (!strcmp(argv[i], "-no-quarter-tail")) p.flags |= NB_FLAG_NO_QUARTER_TAIL;
         else if (!strcmp(argv[i], "-allreduce")) p.flags |= NB_FLAG_SHARD_ALLREDUCE;
         else if (!strcmp(argv[i], "-late-us") && i + 1 < argc) p.sym_late_us = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "-sync-every") && i + 1 < argc) sync_every = atoi(argv[++i]);

@@ -67,7 +67,6 @@ class Simulation:
         sym_tile: int = 0,
         pos_rows: int = 0,
         static_items: bool = False,
-        quarter_tail: bool = True,
         library=None,
     ):
         """The last arguments (from ``uniform_mass`` on) are ``nb_params.flags`` and the launch-geometry tuning fields
@@ -105,7 +104,7 @@ class Simulation:
                    | (L.NB_FLAG_SHARD_SINGLE if shard_single else 0)
                    | (L.NB_FLAG_MASS_SCALING_MEASURED if mass_scaling == "measured" else L.NB_FLAG_MASS_SCALING if mass_scaling is True
                       else L.NB_FLAG_NO_MASS_SCALING if mass_scaling is False else 0)
-                   | (L.NB_FLAG_STATIC_ITEMS if static_items else 0) | (0 if quarter_tail else L.NB_FLAG_NO_QUARTER_TAIL))
+                   | (L.NB_FLAG_STATIC_ITEMS if static_items else 0))
         p.sym_chunks_per_item, p.sym_aux_stream, p.sym_late_us, p.lanes_p = sym_chunks_per_item, sym_aux_stream, sym_late_us, lanes_p
         if sym_tail is not None:
             p.sym_tail[0], p.sym_tail[1], p.sym_tail[2] = sym_tail

@@ -170,7 +170,7 @@ def test_create_argument_validation():
     assert not lib.nb_create(b.ctypes.data, 16, C.byref(p)) and b"exceeds" in lib.nb_last_error()
     p = L.default_params(); p.precision, p.rsqrt_mode = L.NB_FP64, L.NB_RSQRT_QUAKE
     assert not lib.nb_create(b.ctypes.data, 16, C.byref(p))
-    for field, bad in (("flags", 4096), ("flags", 64), ("flags", 128), ("extras", 8),     # 64 / 128: the two experimental step fusions of ABI 4, removed; 1024 / 2048 are ABI 6 bits
+    for field, bad in (("flags", 2048), ("flags", 64), ("flags", 128), ("extras", 8),     # 64 / 128: the two experimental step fusions of ABI 4, removed; 1024 is an ABI 6 bit
                         ("sym_tile", 1024), ("_reserved0", 1), ("sym_chunks_per_item", -1), ("sym_aux_stream", 2), ("lanes_p", 3), ("j_slices", -2)):
         p = L.default_params(); setattr(p, field, bad)
         assert not lib.nb_create(b.ctypes.data, 16, C.byref(p)) and lib.nb_last_error_code() == L.NB_EINVAL, field

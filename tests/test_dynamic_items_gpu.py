@@ -91,45 +91,3 @@ def test_the_ticket_counters_wrap_around_2_to_the_32():
         got = s.sync().copy()
     assert _same(got, want)
 
-
-@pytest.mark.parametrize("which", ["reference default start", "plummer equal masses", "plummer quake", "plummer folded masses"])
-def test_quarter_items_of_the_last_round_change_nothing_but_the_rounding(which, nbo):
-    """Round 6: at the reference's own size (25 000 bodies: 2 450 wave-split items = 9.57 rounds on 256 CUs) the items of the last,
-    partly filled round are re-cut into one-chunk QUARTER items (nb_plan.h SYM_ITEM_QUARTER: the 4 waves share out the stationary
-    particles).  Same pairs, same slab rows, another grouping of the partial sums: the accelerations agree with the uncut plan
-    (NB_FLAG_NO_QUARTER_TAIL) to 1e-6 of the force scale, both sit equally close to the fp64 direct sum, and a trajectory of 20
-    steps stays inside north_star's 1e-5."""
-    from conftest import max_rel
-    n = 25000
-    eps = 1.0 if which.startswith("reference") else 0.05
-    if which.startswith("reference"):
-        ic, kw = nb.default_ics(n), dict(extras=3)
-    else:
-        ic = nb.plummer_2d(n, 13)
-        kw = dict(rsqrt="quake") if "quake" in which else dict()
-        if "folded" in which:
-            ic["mass"] = (np.random.default_rng(3).uniform(0.5, 1.5, n) / n).astype(np.float32)
-            kw = dict(mass_scaling=True)
-    res = {}
-    for quarter in (False, True):
-        with nb.Simulation(ic, eps=eps, quarter_tail=quarter, **kw) as s:
-            info = s.sym_info()
-            acc = s.accelerations().astype(np.float64)
-            s.advance(20, 1e-3)
-            res[quarter] = (info, acc, s.sync().copy(), s.describe())
-    (i0, a0, b0, d0), (i1, a1, b1, d1) = res[False], res[True]
-    cus = i0["cus"]
-    assert i0["tile_particles"] == 512 and i0["chunks_per_item"] == 4 and i0["items"] == 2450
-    if 2450 % cus:
-        assert i1["items"] > i0["items"] and i1["units_local"] == i0["units_local"] and i1["slab_r_bytes"] == i0["slab_r_bytes"]
-    if "folded" in which:
-        assert "mass_scaled=1" in d1 and "mass_scaled=1" in d0
-    scale = np.max(np.abs(a0))
-    assert np.max(np.abs(a1 - a0)) <= 1e-6 * scale, np.max(np.abs(a1 - a0)) / scale
-    assert max_rel(b1["pos"], b0["pos"]) < 1e-5 and max_rel(b1["vel"][1:], b0["vel"][1:]) < 1e-5
-    if "quake" not in which:            # ... and neither plan is the closer one to the fp64 direct sum (Quake's own error is 1e-3)
-        st = nbo.state_from_bodies(ic, np.float64)
-        ax, ay = nbo.accel_f64(st, np.float32(eps))
-        ref = np.stack([ax, ay], 1)
-        e0, e1 = np.max(np.abs(a0 - ref)) / scale, np.max(np.abs(a1 - ref)) / scale
-        assert e1 < (2e-4 if "folded" in which or which.startswith("reference") else 2e-5) and e1 < 1.5 * e0 + 1e-7, (e0, e1)

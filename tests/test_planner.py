@@ -69,15 +69,13 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world, tile):
         # slab rows: stationary rows unique and dense per rank
         assert sorted(items["s_row"]) == list(range(len(items)))
         check_slab_ranges(items, info, n)
-        groups = items["group"].astype(np.int64) & 0xff      # bit 8 (SYM_ITEM_QUARTER) marks the quarter items of a wave-split plan's last round
+        groups = items["group"].astype(np.int64)
         assert (np.diff(groups) >= 0).all() and (groups[:nloc] == 0).all() and (groups[nloc:] > 0).all()
         assert (groups == 2).any() == (world >= 8)           # from 8 ranks on a rank holds some local items back (late)
         w = 0
         for it in items:
-            tile, c0, cnt, diag, group = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"]), int(it["group"]) & 0xff
+            tile, c0, cnt, diag, group = int(it["tile"]), int(it["c0"]), int(it["cnt"]), int(it["diag"]), int(it["group"])
             assert 1 <= cnt <= Lc and c0 + cnt <= chunks
-            if int(it["group"]) & 0x100:             # quarter item: one chunk, whole systems on wave-split tiles only
-                assert cnt == 1 and SB == 512 and world == 1 and group == 0
             if group == 2:
                 assert cnt <= 2
             if group != 1:   # pairs inside the rank's own block: tile and chunks both in block `rank`
@@ -101,40 +99,6 @@ def test_items_cover_every_tile_chunk_pair_exactly_once(n, world, tile):
         assert (cover[tile, :first] == 0).all(), tile      # earlier chunks belong to the earlier tile's items
     if world > 1:
         assert max(work) / (sum(work) / world) < 1.02       # equal local blocks + equal cross runs
-
-
-def test_quarter_items_refill_the_last_round_of_a_wave_split_plan():
-    """Round 6: a wave-split plan of a whole system below 49 152 bodies is `items` workgroups of one chunk
-    per wave — 2 450 of them at the reference's own N = 25 000, i.e. 9.57 rounds on 256 CUs.  The items of the last, partly filled
-    round (items mod CUs, at the END of the list = the order workgroups start in) are re-cut into one-chunk QUARTER items (the 4
-    waves share out the STATIONARY particles): mixed item sizes in one plan, the exact-once cover, the unique slab rows and the
-    travelling-slab tiling unchanged (the generic test above runs on this plan too).  NB_FLAG_NO_QUARTER_TAIL keeps the old plan."""
-    n, cus = 25000, 256
-    old, iold = plan(n, 0, 1, flags=L.NB_FLAG_NO_QUARTER_TAIL)
-    new, inew = plan(n, 0, 1)
-    assert iold["items"] == 2450 and not (old["group"] & 0x100).any() and iold["chunks_per_item"] == 4
-    rem = iold["items"] % cus
-    assert rem == 146
-    q = (new["group"] & 0x100) != 0
-    assert q.sum() == int(old["cnt"][-rem:].sum()) and inew["items"] == iold["items"] - rem + q.sum()
-    assert not q[:iold["items"] - rem].any() and q[iold["items"] - rem:].all()            # exactly the tail of the list
-    assert (new["cnt"][q] == 1).all() and (new[~q]["cnt"] == old[:iold["items"] - rem]["cnt"]).all()
-    for f in ("tile", "c0", "cnt", "diag"):                                                # everything before the tail is the same plan
-        assert np.array_equal(new[f][:iold["items"] - rem], old[f][:iold["items"] - rem]), f
-    # the quarter items are the re-cut of the old tail, chunk by chunk, diagonal ones included
-    want = [(int(it["tile"]), int(it["c0"]) + c, int(it["diag"])) for it in old[-rem:] for c in range(int(it["cnt"]))]
-    assert [(int(it["tile"]), int(it["c0"]), int(it["diag"])) for it in new[q]] == want
-    assert inew["units_local"] == iold["units_local"] and inew["slab_r_bytes"] == iold["slab_r_bytes"]
-    assert inew["rows_s"] == inew["items"] and sorted(new["s_row"]) == list(range(inew["items"]))
-    # not below two full rounds (the rule is for the regime measured), not on classic tiles, not with chunk pairs, not on sharded plans
-    for n2, kw in ((7168, {}), (25000, {"sym_tile": 2048}), (70001, {}), (131072, {"sym_tile": 512})):
-        it2, _ = plan(n2, 0, 1, **kw)
-        assert not (it2["group"] & 0x100).any(), (n2, kw)
-    it8, _ = plan(262144, 3, 8)
-    assert not (it8["group"] & 0x100).any()
-    # another CU count, another remainder: the rule follows `cus`
-    it3, i3 = plan(n, 0, 1, cus=240)
-    assert ((it3["group"] & 0x100) != 0).sum() == int(old["cnt"][-(2450 % 240):].sum())
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
@@ -218,7 +182,7 @@ def test_small_system_plans_follow_the_measured_rules():
     9.1 + 7.3 x ceil(items / CUs) us, what counts is the count — then 8 chunks per item with the late tail up to the classic tiles'
     size; classic plans start the tail early only between 1.5 and 5 rounds of workgroups."""
     for n in (5632, 7168, 10000, 16384, 25000, 36000, 40000):
-        items, info = plan(n, 0, 1, flags=L.NB_FLAG_NO_QUARTER_TAIL)       # the uniform plan itself; round 6 re-cuts its last round (next test)
+        items, info = plan(n, 0, 1)
         tiles = info["tiles"]
         assert info["tile_particles"] == 512 and info["chunks_per_item"] == 4 and info["items"] <= 25 * 256
         # uniform: every item holds 4 chunks except the one remainder per (tile, kind); the minimum possible count
