@@ -213,8 +213,12 @@ def frame_costs(make, ms_per_step_hint, dt):
       step_copy       the same + the caller's own copy of `bodies` (SHARED_BODIES = simulation->bodies)
       overlapped_copy nb_snapshot_begin / _wait: frame k's transfer behind step k + 1, one frame late (Simulation::step_overlapped)
       resident        nb_step(frames) + nb_wait: nothing leaves the device."""
+    import ctypes
     frames = int(min(300, max(20, 400.0 / max(ms_per_step_hint, 1e-3))))
     out = {"frames": frames}
+
+    def copy(dst, src):          # the caller's `SHARED_BODIES = simulation->bodies`: one memcpy of the records (numpy would copy field by field)
+        ctypes.memmove(dst.ctypes.data, src.ctypes.data, src.nbytes)
     with make() as g:
         shared = g.bodies.copy()
         g.advance(3, dt)
@@ -226,7 +230,7 @@ def frame_costs(make, ms_per_step_hint, dt):
         t0 = time.perf_counter()
         for _ in range(frames):
             g.step(dt)
-            shared[:] = g.bodies
+            copy(shared, g.bodies)
         out["step_copy"] = (time.perf_counter() - t0) / frames * 1e3
         back, inflight = g.bodies.copy(), False
         t0 = time.perf_counter()
@@ -234,7 +238,7 @@ def frame_costs(make, ms_per_step_hint, dt):
             g.advance(1, dt)
             if inflight:
                 g.snapshot_wait()
-                shared[:] = back
+                copy(shared, back)
             g.snapshot_begin(back)
             inflight = True
         g.snapshot_wait()
@@ -930,10 +934,31 @@ def torchrun_available() -> bool:
 
 
 def _free_port() -> int:
+    """A TCP port for a rendezvous on 127.0.0.1, chosen BELOW the kernel's ephemeral range (ip_local_port_range, 32768-60999 here).
+    The usual bind(0)-close-reuse pattern hands back an ephemeral port, and between the close and the rendezvous server's own bind
+    the kernel may give that very port to an outgoing connection — including the waiting rank's own connect() retries, which can
+    "self-connect" to a local port nobody listens on yet; the server then dies with EADDRINUSE (seen once in round 6 on a GPU box).
+    Ports below the range are only ever taken by explicit binds: probing one and using it a second later is safe in practice."""
+    import random
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    lo, hi = 20000, 32000
+    try:
+        first = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+        hi = min(hi, first - 1) if first > lo + 1000 else hi
+    except (OSError, ValueError, IndexError):
+        pass
+    rng = random.SystemRandom()
+    for _ in range(200):
+        port = rng.randrange(lo, hi)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    with socket.socket() as s:              # nothing free down there (never seen): the old way
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def _die_with_parent():
@@ -1112,10 +1137,7 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal and "MASTER_PORT" not in os.environ:        # plain `python bench.py --rehearse-sharded`: a process group of one
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(_free_port())
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         # no wait without an end: the process group's own collective timeout (its watchdog aborts the process) and, around the

@@ -159,7 +159,7 @@ static int bind(const nb_sim *s)
 // Launch geometry of one one-sided force job.  The kernel is VALU-bound, so what
 // matters is (a) enough independent work per lane — 2P particles per lane, P = 4 measured best — and
 // (b) enough workgroups in flight to keep 5-8 waves per SIMD issuing and to even out the tail: about
-// 32 workgroups per CU (profiles/r01_force_tiled_geometry_sweep.log).  When i-particles are scarce (sharded or small runs)
+// 32 workgroups per CU (profiles/history/r01_force_tiled_geometry_sweep.log).  When i-particles are scarce (sharded or small runs)
 // the j range is cut into more tile-aligned slices (at most 128: every slice is a slab that
 // `integrate` re-reads), and P drops only when even that cannot fill half the target.
 static bool want_sym(const nb_sim *s);
@@ -186,7 +186,7 @@ static ForceJob plan_job(const nb_sim *s, uint32_t jb, uint32_t je, uint32_t sla
     // particles -> 128P particles per workgroup; fp64: 256 i-lanes, P particles per lane.
     const uint32_t lanes_i = s->fp64 ? 1u : 2u;                 // particles per lane per P
     const uint32_t ilanes = s->fp64 ? (uint32_t)BLOCK : (uint32_t)BLOCK / F32_WS;
-    const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (profiles/r01_force_tiled_geometry_sweep.log)
+    const uint32_t target = 32u * (uint32_t)s->cus;             // workgroups wanted in the grid (profiles/history/r01_force_tiled_geometry_sweep.log)
     const uint32_t max_slices = 128;                            // bounds the slab traffic of `integrate`
     const uint32_t tiles = (jn + TJ - 1) / TJ;
     const int forced_p = s->p.lanes_p > 0 ? s->p.lanes_p : 0;
@@ -232,7 +232,7 @@ static bool needs_guard(const nb_sim *s) { return s->fp64 ? !(s->p.eps > 0.0f) :
 // workgroup share the stationary particles and split the chunks) give the planner work units a quarter the size, items
 // whose stationary row is 4 KiB instead of 16, and a sweep without barriers — what small and mid-size systems need to
 // fill 1024 resident workgroup slots evenly — for four times the travelling partials per pair, which large systems do not
-// pay back.  Measured (profiles/r04_ws_sweep.log): -3 ... -4 % step time at N = 25 000 (reference
+// pay back.  Measured (profiles/history/r04_ws_sweep.log): -3 ... -4 % step time at N = 25 000 (reference
 // workload), -2.5 % at 16 384 and 32 768, neutral at 65 536, +1.3 ... +2.6 % at 131 072: used below 49 152 bodies.
 // fp32 2-D, single handle (a rank of a sharded run keeps the classic tiles: its blocks are whole 2048-particle tiles).
 // nb_params.sym_tile = 512 / 2048 forces one.  Rank-independent (n and parameters only).
@@ -252,7 +252,7 @@ static bool sym_eligible(const nb_sim *s)
     // smallest system worth the symmetric scheme: 16 384 bodies with the classic tiles (rounds 1-3); with the wave-split tiles and
     // their uniform one-chunk-per-wave plans it overtakes the one-sided kernel from ~5 600 bodies on (-4 ... -8 % at 5 632, -14 ... -17 %
     // at 6 144, -24 ... -28 % at 7 168, -32 ... -34 % at 10 000; +1 ... +6 % at 5 120, +25 % at 4 096:
-    // profiles/r04_small_n_plans.log)
+    // profiles/history/r04_small_n_plans.log)
     if (s->n < (sym_tile_of(s->p, s->n) == SYM_SB_WS ? (size_t)5632 : 8 * (size_t)SYM_SB)) return false;
     const uint32_t world = s->p.shard_world > 1 ? (uint32_t)s->p.shard_world : 1u;
     // Travelling partials: one element per (tile, later particle) pair the handle evaluates — tiles x n / 2 for a
@@ -304,7 +304,7 @@ static bool want_sym_sharded(const nb_sim *s)  // rank of a sharded run
 // measured 35 units/us (fp32) or 14 (fp64) of 256 CUs.  Alone on the chip those items take 50-60 us and the
 // hand-over between the streams ~15 us, so the split pays when the collective is exposed for longer than that
 // share of a step: from 8 ranks on (a rank's step at N = 262 144 is ~1 ms there; at 2-4 ranks it measured
-// neutral to -2 %, profiles/r01_late_items_ab.log).  nb_params.sym_late_us > 0 forces it for any world size,
+// neutral to -2 %, profiles/history/r01_late_items_ab.log).  nb_params.sym_late_us > 0 forces it for any world size,
 // < 0 disables it.
 static uint32_t late_units_for(const nb_params &p, bool fp64, int cus, uint32_t world)
 {
@@ -315,7 +315,7 @@ static uint32_t late_units_for(const nb_params &p, bool fp64, int cus, uint32_t 
 
 // Chunk PAIRS (sym_chunks2: two travelling particles per lane) pay from ~65 536 bodies on (-2 ... -3 % at 131 072 - 262 144,
 // neutral at 65 536; below that the coarser items and the lower occupancy — 146-158 VGPRs, 3 waves per SIMD — cost more
-// than the saved rotations: profiles/r03_chunk_pairs_sweep.log).  fp32 2-D only.  nb_params.sym_chunk_pairs = 1 / -1 forces it.
+// than the saved rotations: profiles/history/r03_chunk_pairs_sweep.log).  fp32 2-D only.  nb_params.sym_chunk_pairs = 1 / -1 forces it.
 // Rank-independent (n and parameters only): it shapes the plan every rank must agree on.
 static bool want_pairs(const nb_params &p, size_t n)
 {
@@ -396,7 +396,7 @@ extern "C" int nb_debug_sym_plan(size_t n, int cus, int rank, int world, const n
 // Round 2 saw one process abort inside nb_upload right after nb_host_register of an unaligned numpy array.  CAUSE
 // UNKNOWN: no log of that run exists, and none of the nine deterministic constructions of round 3's pin probe (shared
 // pages, overlapping registrations, freed-while-registered memory reused at the same address ...) aborts on this
-// runtime (profiles/r03_pin_probe.log).  The rules above are therefore a DEFENSIVE change, not the fix of a known bug.
+// runtime (profiles/history/r03_pin_probe.log).  The rules above are therefore a DEFENSIVE change, not the fix of a known bug.
 struct PinnedRange { uintptr_t lo, hi; bool owned; };
 static std::mutex g_pin_mutex;
 static std::vector<PinnedRange> g_pinned;
@@ -419,7 +419,10 @@ static size_t host_page_size()
 constexpr size_t BOUNCE_SLOTS = 4;
 constexpr size_t BOUNCE_SLOT_BYTES = (size_t)2 << 20;       // 4 x 2 MiB: a DMA, a host memcpy and two slots of slack in flight
 constexpr size_t BOUNCE_BYTES = BOUNCE_SLOTS * BOUNCE_SLOT_BYTES;
-constexpr size_t SMALL_SYNC_BYTES = (size_t)4 << 20;      // nb_sync: below this the pack kernel writes the host staging buffer itself (no DMA)
+#ifndef NB_SMALL_SYNC_BYTES
+#define NB_SMALL_SYNC_BYTES ((size_t)4 << 20)           // (A/B builds: -DNB_SMALL_SYNC_BYTES=0 keeps the copy-engine path for every size)
+#endif
+constexpr size_t SMALL_SYNC_BYTES = NB_SMALL_SYNC_BYTES;   // nb_sync: below this the pack kernel writes the host staging buffer itself (no DMA)
 
 static int ensure_bounce(nb_sim *s)
 {
@@ -548,7 +551,7 @@ static int plan_sym(nb_sim *s)
     // Side stream for the local items when they are about one wave of workgroups (P = 8 at N = 262 144: 615 items
     // on 512 resident slots, 150 us where 128 us of work is due): run concurrently, the cross items fill the CUs
     // the last local workgroups leave idle (-1.7 % step time; with two LONG launches sharing the chip, P = 2, the
-    // same trick costs 4 % — profiles/r01_aux_stream_ab.log — hence the bound).  nb_params.sym_aux_stream = 1 / -1 forces it.
+    // same trick costs 4 % — profiles/history/r01_aux_stream_ab.log — hence the bound).  nb_params.sym_aux_stream = 1 / -1 forces it.
     s->aux_local = s->sym_sharded && (s->p.sym_aux_stream ? s->p.sym_aux_stream > 0 : s->sym_items_local <= 4u * (uint32_t)s->cus);
     if (s->aux_local || s->sym_items_late) {         // the late items always run on the side stream
         HIPCHK(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
@@ -992,7 +995,7 @@ static int launch_sym_items(nb_sim *s, uint32_t first, uint32_t count, hipStream
         float4 *ss = (float4 *)s->sym_slab_s, *sr = (float4 *)s->sym_slab_r;
 #define NB_SYM3_LAUNCH(RQ, UMB, PR, UMV) do { NB_TICKETS((force_sym3_f32<RQ, UMB, PR>)); force_sym3_f32<RQ, UMB, PR><<<count, BLOCK, 0, st>>>(pos, items, ss, sr, n, eps2, UMV, tk, fw, tb); } while (0)
         // chunk pairs in 3-D pay with equal masses only (-1 ... -3 %); with individual masses the pair body needs 216 VGPRs
-        // (2 waves per SIMD) and loses 4 % (profiles/r03_chunk_pairs_3d.log): that case keeps the single-chunk sweep
+        // (2 waves per SIMD) and loses 4 % (profiles/history/r03_chunk_pairs_3d.log): that case keeps the single-chunk sweep
         // (any plan, even chunk counts included, runs on either kernel) unless nb_params.sym_chunk_pairs = 1 forces it
         const bool pairs = s->sym_pairs && (s->uniform_mass || s->p.sym_chunk_pairs > 0);
         if (s->uniform_mass) {

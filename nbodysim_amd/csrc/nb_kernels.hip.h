@@ -45,7 +45,7 @@ template <> struct vec2_of<double> { typedef double2 type; };
 
 // Slab stores of the symmetric kernels.  WT = write-through (`sc1`): the bytes leave this XCD's L2 for memory at once instead of
 // staying dirty there until the kernel's end flushes them — the partials are read by the NEXT launch only (force_sym_f32 below:
-// -1.8 % step time at N = 25 000, -0.7 % at 65 536, neutral at 262 144, same bits; profiles/r04_write_through_ab.log).
+// -1.8 % step time at N = 25 000, -0.7 % at 65 536, neutral at 262 144, same bits; profiles/history/r04_write_through_ab.log).
 // WT = false is the plain store.
 template <bool WT>
 __device__ __forceinline__ void store8(float2 *p, float2 v)
@@ -802,7 +802,7 @@ void force_sym_f32_body(const float2 *__restrict__ pos, const float *__restrict_
 // Which item a workgroup runs.  Workgroups are dealt round-robin over the 8 XCDs and every XCD walks ITS share in index order
 // (tools/sym_timeline.hip: no inversion inside an XCD, XCDs up to 8 % of a launch apart), so with item = blockIdx every XCD gets
 // the same work — and the XCDs of one part are not equally fast: the same XCDs end 2-5 % before the others launch after launch,
-// whatever items they were dealt (profiles/r04_xcd_speed.log), and stand idle until the slowest is through.  With `ticket` set, the
+// whatever items they were dealt (profiles/history/r04_xcd_speed.log), and stand idle until the slowest is through.  With `ticket` set, the
 // workgroups of the first wave (blockIdx < first_wave: they start together, an atomic each would only queue them up) keep their
 // static item and every later workgroup draws the next item of the list when it STARTS: a faster XCD starts more workgroups and so
 // takes more items.  The counter is monotonic over the handle's life (base = what earlier launches drew); any order gives the same
@@ -829,7 +829,7 @@ void force_sym_f32(const float2 *__restrict__ pos, const float *__restrict__ mas
 #ifndef NB_SYM_WT
 #define NB_SYM_WT true       // write-through (sc1) slab stores: the partials are read by the NEXT launch only, so nothing is gained by
 #endif                       // keeping them dirty in this XCD's L2 until the kernel's end flushes them: -1.8 % step time at N = 25 000,
-                             // -0.7 % at 65 536, neutral at 262 144, same bits (profiles/r04_write_through_ab.log)
+                             // -0.7 % at 65 536, neutral at 262 144, same bits (profiles/history/r04_write_through_ab.log)
     force_sym_f32_body<RSQ, MM, PAIRS, WS, NB_SYM_WT>(pos, mass, sigma, items[sym_item_index(ticket, first_wave, ticket_base)], slab_s, slab_r, n, eps2, um_mass);
 }
 

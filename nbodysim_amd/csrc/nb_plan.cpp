@@ -76,26 +76,26 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
         if (g.block_of(I) == rank || world == 1) local += be - I * g.cpt;       // own chunks (diagonal) + later chunks of the block
         cross_total += chunks - be;
     }
-    // workgroups wanted (profiles/r01_*sweep.log): with the guided tail 24 per CU run as fast as 32 (L = 43-48 vs 33
+    // workgroups wanted (profiles/history/r01_*sweep.log): with the guided tail 24 per CU run as fast as 32 (L = 43-48 vs 33
     // at N = 262 144) and write a quarter fewer slab rows
     // (a sharded rank of the reduce-scatter protocol runs its local and its cross items as two launches with a tail
-    // each: 24 per CU there too — profiles/r02_shard_L_sweep.log: -2.5 % at 4 ranks, neutral at 8; the single launch of
+    // each: 24 per CU there too — profiles/history/r02_shard_L_sweep.log: -2.5 % at 4 ranks, neutral at 8; the single launch of
     // a replicated rank is best at 16)
     const uint32_t target = (tune.wg_per_cu ? tune.wg_per_cu : (world > 1 ? 16u : 24u)) * cus;
     // Chunks per item.  Large systems: as many items as fill the chip `target` workgroups deep.  Small ones
     // (fewer chunk-units than that): one chunk per item would be the finest grain, but every item costs a
     // 16-KiB slab row that sym_gather re-reads and a prologue, while coarse items cost tail — the optimum
-    // sits near items ~ 20 sqrt(units) at 256 CUs (profiles/r01_force_sym_small_n_sweep.log: L = 2 at
+    // sits near items ~ 20 sqrt(units) at 256 CUs (profiles/history/r01_force_sym_small_n_sweep.log: L = 2 at
     // N = 16 384, 3 at 25 000-32 768, 4-6 at 65 536, -5 ... -10 % step time against L = 1).
     const uint64_t units = local + cross_total / world;
     uint32_t L = tune.forced_L;
     if (!L) {
         const uint32_t fill = (uint32_t)((units + target - 1) / target);
         // (round 4, wave-split kernels and chunk pairs in place: items ~ 16 sqrt(units) with an earlier tail measures 1-2 % faster at
-        // N = 25 000 ... 65 536 than the 20 sqrt(units) of round 1; profiles/r04_tail_sweep.log)
+        // N = 25 000 ... 65 536 than the 20 sqrt(units) of round 1; profiles/history/r04_tail_sweep.log)
         // A rank of a sharded run gets 12 chunks per item at 8 ranks instead of 10 (one rank's compute share on one GPU: 94.3 ->
         // 95.5 % of the ideal in the symmetric protocol, 94.3 -> 96.4 % in the all-reduce protocol), 16 instead of 14 at 4 ranks and
-        // 22 at 2 ranks (both unchanged within the noise); its tail thresholds stay (profiles/r04_rank_tail_sweep.log).
+        // 22 at 2 ranks (both unchanged within the noise); its tail thresholds stay (profiles/history/r04_rank_tail_sweep.log).
         const uint32_t grain = (uint32_t)(std::sqrt((double)units) * 256.0 / (16.0 * (double)cus) + 0.5);
         L = fill > grain ? fill : grain;
     }
@@ -105,7 +105,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     if (unit > 1 && !tune.forced_L) L = L < unit ? unit : ((L + unit / 2) / unit) * unit;
     // WAVE-SPLIT plans of whole systems (round 4; tiles of 512, N < 49 152): the finest uniform items and NO guided tail.  With one
     // chunk per wave a workgroup is one chunk time long (7.3 us with equal masses), a CU holding k of them takes k chunk times, and
-    // the measured step is 9.1 + 7.3 x ceil(items / CUs) us from 7 168 to 25 000 bodies (profiles/r04_small_n_plans.log) — what
+    // the measured step is 9.1 + 7.3 x ceil(items / CUs) us from 7 168 to 25 000 bodies (profiles/history/r04_small_n_plans.log) — what
     // counts is the item COUNT.  Tail pieces of such items hold fewer chunks than the workgroup has waves (idle waves, nothing
     // gained) and only raise the count; coarser items (the rule above: ~16 sqrt(units)) quantise the same work into fewer, longer
     // rounds.  Against the plans of earlier in the round: -21 % per step at N = 7 168 / 10 000 / 11 000, -16 % at 13 312, -8 ... -10 %
@@ -129,7 +129,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // rank r takes sub-range (r + I) mod world of tile I.  Every rank therefore holds a slice of every tile: its stationary
     // rows and travelling segments — and with them the work of its sym_gather — are spread over all tiles instead of
     // piling up on the few tiles a contiguous run of the tile-major item list covers (round 2: a rank's gather ran at
-    // 1.7 TB/s on ~20 heavy tiles; profiles/r03_shard_p8_*).  The sub-ranges of a tile partition [be, chunks) exactly, so
+    // 1.7 TB/s on ~20 heavy tiles; profiles/history/r03_shard_p8_*).  The sub-ranges of a tile partition [be, chunks) exactly, so
     // all ranks together still meet every (tile, chunk) pair once; shares differ by at most one unit per tile, rotated
     // over the ranks.  Units are chunk pairs for handles that sweep pairs (even_chunks).
     std::vector<SymItem> local_items, cross_items, late_items;
@@ -183,7 +183,7 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
     // Guided tail: workgroups are dispatched in item order and an item is a fixed amount of VALU work, so a
     // launch ends with up to one item time of partly idle CUs (half of it on average: 3 % of a single-GPU step,
     // 7 % of a rank's step at world = 8).  The end of each launch's work is cut into finer items
-    // (L/2, L/4, L/8 chunks from 85 %, 94 %, 98 % of the work on; profiles/r01_guided_tail_ab.log): -2 % step time.
+    // (L/2, L/4, L/8 chunks from 85 %, 94 %, 98 % of the work on; profiles/history/r01_guided_tail_ab.log): -2 % step time.
     // Splitting happens after the cross runs were assigned, so every rank still sees the same run boundaries.
     if (tune.guided_tail && !no_tail) {
         auto guided = [&](std::vector<SymItem> &list, std::vector<uint32_t> &rows_of) {
@@ -192,10 +192,10 @@ void build_sym_plan(uint32_t n, uint32_t cus, uint32_t rank, uint32_t world, con
             // A launch of few rounds (items per resident workgroup slot, ~4 slots per CU) ends with a larger share of its work in the
             // last, partly filled round: the finer items start earlier there (0.65 / 0.85 / 0.95 below 5 rounds instead of 0.85 / 0.94 /
             // 0.98: -9 % at N = 16 384 (with tail pieces of fewer chunks than waves), -1 % at 65 536, +-1 % elsewhere, the headline plan
-            // — 6 100 items before the tail is cut, 8 187 after: 6 rounds — unchanged; profiles/r04_tail_sweep.log, r04_defaults_check.log).  Explicit
+            // — 6 100 items before the tail is cut, 8 187 after: 6 rounds — unchanged; profiles/history/r04_tail_sweep.log, r04_defaults_check.log).  Explicit
             // thresholds (nb_params.sym_tail) are taken as given.  Not below 1.5 rounds either: there the extra items of an early tail cost
             // more than they balance (classic tiles, fp64 / 3-D handles at 16 384 ... 24 576 bodies: the late tail is 4-9 % faster;
-            // profiles/r04_small_n_plans_classic.log).
+            // profiles/history/r04_small_n_plans_classic.log).
             double at[3] = {tune.tail_at[0], tune.tail_at[1], tune.tail_at[2]};
             if (!tune.tail_given && world == 1 && !late_tail && (double)list.size() >= 1.5 * 4.0 * (double)cus && (double)list.size() < 5.0 * 4.0 * (double)cus)
                 { at[0] = 0.65; at[1] = 0.85; at[2] = 0.95; }

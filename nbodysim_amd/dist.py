@@ -235,6 +235,13 @@ def agree_on_fastest(local_seconds: Dict[str, float], group=None,
     return best, job
 
 
+def after_collectives(err: BaseException) -> BaseException:
+    """Mark ``err`` as raised at a point where this rank has issued every collective its peers expect of it (or where every rank
+    raises together): ``time_candidates`` may then let the ranks agree on the failure instead of ending the job."""
+    err.collectives_complete = True      # type: ignore[attr-defined]
+    return err
+
+
 def time_candidates(names: Sequence[str], run_one: Callable[[str, Dict[str, float]], float], group=None, deadline_s: float = 120.0,
                     rank: int = 0, prefer: Sequence[str] = (), log: Optional[Callable[[str], None]] = None,
                     cleanup: Optional[Callable[[str], None]] = None, failed: Optional[Dict[str, str]] = None):
@@ -246,8 +253,13 @@ def time_candidates(names: Sequence[str], run_one: Callable[[str, Dict[str, floa
     A candidate that RAISES on any rank (and leaves its peers able to go on: see ``DistributedSimulation.step``, which keeps
     issuing a failed rank's collectives) is not the end of the run: after every candidate the ranks agree on whether it
     completed everywhere (one all-reduce); if not it counts as unavailable on ALL of them, ``cleanup(name)`` runs (errors
-    ignored), ``failed[name]`` says why, and the next candidate is tried.  Returns (winner, {name: job seconds}) from
-    ``agree_on_fastest`` — which raises only if nothing at all survived."""
+    ignored), ``failed[name]`` says why, and the next candidate is tried.  That agreement is itself a collective, so it is
+    entered only for a failure that is KNOWN to have left this rank in step with its peers: ``run_one`` marks such an error with
+    ``after_collectives(err)`` — raised once the trial's last collective was through, or raised by every rank together.  Anything
+    else (a C-loop step that failed half-way through its schedule, an exception before the trial's barriers) is re-raised at
+    once: this rank's next collective would pair with a DIFFERENT one of its peers', and the launcher tearing the job down now
+    is the only safe outcome.  Returns (winner, {name: job seconds}) from ``agree_on_fastest`` — which raises only if nothing
+    at all survived."""
     local: Dict[str, float] = {}
     failed = {} if failed is None else failed
     for name in names:
@@ -255,7 +267,9 @@ def time_candidates(names: Sequence[str], run_one: Callable[[str, Dict[str, floa
             err: Optional[BaseException] = None
             try:
                 value = float(run_one(name, local))
-            except Exception as e:       # noqa: BLE001 - whatever it was, the other candidates still deserve their turn
+            except Exception as e:       # noqa: BLE001 - whatever it was, the other candidates still deserve their turn ...
+                if not getattr(e, "collectives_complete", False):
+                    raise                # ... unless this rank may be out of step with its peers: no further collective from here
                 err, value = e, float("inf")
             _, lo, _ = ranks_agree([0 if err is not None else 1], group)
             if lo[0] == 0:
@@ -641,7 +655,7 @@ class DistributedSimulation:
                 self._create(bodies, cand, extra, d)
             except RuntimeError as e:                             # raised on EVERY rank (agreed inside _create)
                 if "not eligible" not in str(e) and "communicator could not be formed" not in str(e):
-                    raise
+                    raise after_collectives(e)
                 return float("inf")
             # From here to the end of the trial EVERY rank walks the same sequence of collectives (steps, barriers, the replica check,
             # the validation gather), whatever happens to its own compute calls: a failed launch is kept pending (_defer_errors) and the
@@ -696,7 +710,7 @@ class DistributedSimulation:
                 sys.stderr.flush()
             self.close()
             if pending is not None:
-                raise pending
+                raise after_collectives(pending)      # deferred through the whole trial (_compute / _defer_errors): the peers are not stranded
             return per_step
 
         def cleanup(name: str) -> None:

@@ -12,6 +12,34 @@ sys.path.insert(0, str(ROOT / "oracle"))
 GOLD = ROOT / "tests" / "golden"
 
 
+def free_port() -> int:
+    """A TCP port for a rendezvous on 127.0.0.1, chosen BELOW the kernel's ephemeral range (ip_local_port_range, 32768-60999 here).
+    The usual bind(0)-close-reuse pattern hands back an ephemeral port, and between the close and the rendezvous server's own bind
+    the kernel may give that very port to an outgoing connection — including the waiting rank's own connect() retries, which can
+    "self-connect" to a local port nobody listens on yet; the server then dies with EADDRINUSE (seen once in round 6 on a GPU box).
+    Ports below the range are only ever taken by explicit binds: probing one and using it a second later is safe in practice."""
+    import random
+    import socket
+    lo, hi = 20000, 32000
+    try:
+        first = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+        hi = min(hi, first - 1) if first > lo + 1000 else hi
+    except (OSError, ValueError, IndexError):
+        pass
+    rng = random.SystemRandom()
+    for _ in range(200):
+        port = rng.randrange(lo, hi)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    with socket.socket() as s:              # nothing free down there (never seen): the old way
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     config.addinivalue_line("markers", "perf: orderings between measured durations (GPU box, -m perf); never part of the correctness suites")

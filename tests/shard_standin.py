@@ -105,7 +105,7 @@ class StandinSharded:
 
     # -- the start-up timing: the REAL time_candidates over stand-in trials ---------------------------------------------
     def _tune(self):
-        from nbodysim_amd.dist import compare_with_unsharded, time_candidates
+        from nbodysim_amd.dist import after_collectives, compare_with_unsharded, time_candidates
 
         steps, names = 3, ["allgather", "allreduce", "symmetric"]
         ref = {}
@@ -128,7 +128,7 @@ class StandinSharded:
                 time.sleep(3600)
             v = compare_with_unsharded(trial.owned_rows(), trial.plan, unsharded, steps)
             if trial._hit("raise"):
-                raise RuntimeError("injected: this rank's trial of '%s' failed" % name)
+                raise after_collectives(RuntimeError("injected: this rank's trial of '%s' failed" % name))     # the trial's collectives are through
             return ({"allgather": 3.0, "allreduce": 1.0}[name]) if v["ok"] else float("inf")
 
         failed = {}

@@ -101,10 +101,8 @@ def test_bench_line_of_a_two_rank_rehearsal():
     """The N > 1 path of bench.py end to end, as the driver launches it (torch.distributed.run, one process per rank),
     rehearsed with two ranks over gloo on this one GPU (RCCL refuses two ranks per device): the autotune's verdict,
     the per-phase report and the contract fields are all there.  Not a scaling measurement."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from conftest import free_port
+    port = free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--nbodies", "32768", "--steps", "4", "--warmup", "1",
                         "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))

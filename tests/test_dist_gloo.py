@@ -13,10 +13,7 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from conftest import free_port as _free_port  # noqa: E402  (below the ephemeral range: see there)
 
 
 def _worker(rank, world, port, n, steps, out_dir):

@@ -20,10 +20,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from conftest import free_port as _free_port  # noqa: E402  (below the ephemeral range: see there)
 
 
 def _worker(rank, world, port, backend, n, steps, precision, out_dir, late_us=None):

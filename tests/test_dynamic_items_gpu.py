@@ -2,7 +2,7 @@
 index (NB_FLAG_STATIC_ITEMS).
 
 Past the first resident wave a workgroup draws the next item of the plan's list when it STARTS, so the XCDs of a part — which are
-not equally fast (profiles/r04_xcd_speed.log) — end together.  Which workgroup runs which item cannot matter: every item writes
+not equally fast (profiles/history/r04_xcd_speed.log) — end together.  Which workgroup runs which item cannot matter: every item writes
 its own slab rows and the gather adds them in a fixed order.  So the bodies must be BIT-IDENTICAL to the static assignment, for
 every kernel family that takes tickets (fp32 / fp64, 2-D / 3-D, both tile sizes, chunk pairs) and for the three launch kinds of a
 sharded rank (local, cross, late items: one counter each).  Replaces the fan-out of `attract()` (Simulation.hpp:180-213)."""

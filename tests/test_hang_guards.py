@@ -30,10 +30,7 @@ ROOT = Path(__file__).resolve().parents[1]
 TESTS = Path(__file__).resolve().parent
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from conftest import free_port as _free_port  # noqa: E402  (below the ephemeral range: see there)
 
 
 def load_bench():
@@ -106,6 +103,25 @@ def test_the_same_timing_completes_and_agrees_when_nobody_stalls():
     for r, (p, (out, err)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, err[-600:]
         assert f"rank {r} chose symmetric ['allgather', 'allreduce', 'symmetric']" in out
+
+
+def test_a_failure_that_may_have_left_the_rank_out_of_step_is_never_agreed_on():
+    """time_candidates' agreement after a failed candidate is a collective.  It is entered only for errors marked
+    with after_collectives() (raised once the trial's collectives were through, or by every rank together); anything else — a C-loop
+    step that died half-way through its schedule — is re-raised at once, so the launcher tears the job down instead of this rank's
+    all-reduce pairing with a peer's barrier.  No process group here: reaching ranks_agree would itself raise."""
+    sys.path.insert(0, str(ROOT))
+    from nbodysim_amd.dist import after_collectives, time_candidates
+    seen = []
+
+    def run_one(name, local):
+        seen.append(name)
+        raise ValueError("mid-sequence failure in " + name)
+    with pytest.raises(ValueError, match="mid-sequence failure in allgather"):
+        time_candidates(["allgather", "allreduce"], run_one, None, 5.0, 0)
+    assert seen == ["allgather"]                                             # nothing else was tried, no collective was issued
+    err = after_collectives(RuntimeError("x"))
+    assert err.collectives_complete is True
 
 
 def test_watchdog_is_inert_inside_its_deadline_and_can_be_disabled():
