@@ -497,6 +497,8 @@ def driver_reason(sim):
     """Which host runs the step loop of a sharded run, and why (from the start-up timing's record)."""
     t = getattr(sim, "tuning", None)
     drv = getattr(sim, "driver", None)
+    if hasattr(sim, "transport"):           # nbodysim_amd.local_ranks.LocalRanksSimulation: no launcher, no process group
+        return f"{drv}: ONE process drives every rank ({sim.transport} transport)"
     if not t:
         return f"{drv}: named on the command line (no start-up timing)" if drv else None
     ms, val, chosen = t.get("ms_per_step", {}), t.get("validation", {}), t.get("chosen", "")

@@ -187,4 +187,5 @@ def test_typed_without_a_launcher_the_ranks_start_as_children_even_here():
     assert "must be launched with" not in r.stderr
     import torch
     if not torch.cuda.is_available():
-        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") == 2 and r.stdout.strip() == ""
+        # (the launcher tears the other rank down as soon as the first one fails: one or two refusals reach stderr)
+        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 1 and r.stdout.strip() == ""
