@@ -30,13 +30,17 @@ Extra objects in the line:
                 kernel evaluates every UNORDERED pair once, so the flops it really
                 issues are fewer: `executed_tflops` / `executed_frac` count those
                 (17 flop per unordered pair) and are the honest "fraction of the
-                ALU peak" figure; `valu_busy` comes from the PMC profile of the round.
-                `traffic` = HBM bytes of one launch of the dominant kernel: the PMC
-                measurement of this command kept under profiles/ (separate rocprofv3
-                --pmc passes, FETCH_SIZE x2 correction) when it exists for this
-                workload, else the figure derived from the work plan (`traffic_plan`:
-                slab rows written + positions read); `traffic_pmc` = the counter
-                measurement kept under profiles/ (cross-check).
+                ALU peak" figure.  `frac_sustained` is the same fraction over the >= 2 s of steps run AFTER
+                the timed region: the settled figure, the one to quote.
+                `valu_busy` and `traffic` (HBM bytes of one launch of the dominant kernel) are COUNTER
+                figures: by default this run collects them itself on this box, after everything that is
+                timed — three separate `rocprofv3 --pmc` passes of this command in its shortest form as
+                child processes (FETCH_SIZE x2 correction; MI355X_MICROARCH.md) — and says so (`pmc_status:
+                "live"`; the committed record of profiles/hbm_traffic.json is carried beside them as
+                `valu_busy_committed` / `traffic_committed`).  With --no-live-pmc, or where the profiler
+                cannot run, the committed record is used if it is of exactly this kernel instantiation, N
+                and work plan; otherwise the fields are null.  The work plan's own estimate (slab rows
+                written + positions read) is `traffic_plan`, never in the counter's place.
   cpu_baseline  the oracle (C restatement of the reference's pairwise loop, the
                 reference's own arithmetic) timed on this box's host cores over
                 a bounded i-slice of the same workload.  Rank 0, --gpus 1 only.
@@ -283,6 +287,66 @@ def pmc_lookup(book, kernel_full, n, items):
     return None, "none"
 
 
+def live_pmc(args, kernel_full, items, timeout_s=75.0):
+    """The PMC figures of THIS run's dominant kernel, collected on THIS box after the timed region: three separate `rocprofv3 --pmc`
+    passes (MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled on gfx950)
+    of this very command in its shortest form (3 steps, nothing but the step loop) as CHILD processes — `rocprofv3 ... -- python3
+    bench.py ...`, the program itself after `--`, nothing exec'ed in place.  Returns (entry or None, status): the entry has the shape
+    of a profiles/hbm_traffic.json record and is accepted only for exactly the kernel instantiation and item count that ran here.
+    Never part of `value`; bounded by `timeout_s` per pass; any failure leaves the counter fields to the committed record or null."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if kernel_full is None:
+        return None, "none: no PMC collection for this kernel"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(rocprof).exists():
+        return None, "none: rocprofv3 not found on this box"
+    work = ["--nbodies", str(args.n), "--precision", args.precision, "--rsqrt", args.rsqrt, "--dims", str(args.dims), "--mass-scaling", args.mass_scaling]
+    work += (["--general-mass"] if args.general_mass else []) + (["--no-symmetry"] if args.no_symmetry else [])
+    work += ["--chunks-per-item", str(args.chunks_per_item)] if args.chunks_per_item else []
+    child = [sys.executable, str(Path(__file__).resolve()), *work, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-events",
+             "--no-sustained", "--no-secondary", "--no-live-pmc"]
+    tmp = tempfile.mkdtemp(prefix="nb_live_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sets = (("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"), ("GRBM_GUI_ACTIVE", "FETCH_SIZE"), ("WRITE_SIZE",))
+    try:
+        for k, counters in enumerate(sets):
+            cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", f"{tmp}/{k}", "--", *child]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"live collection failed: pass {k} ({' '.join(counters)}) exceeded {timeout_s:.0f} s"
+            if r.returncode != 0:
+                return None, f"live collection failed: pass {k} ({' '.join(counters)}) ended with status {r.returncode}: {(r.stderr or r.stdout)[-160:]!r}"
+        vals, grid = {}, None
+        for f in glob.glob(f"{tmp}/*/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Kernel_Name"].split("(")[0].replace("void ", "") != kernel_full:
+                    continue
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                grid = int(row.get("Grid_Size") or 0) // 256 or grid
+        need = ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE")
+        if any(c not in vals for c in need):
+            return None, f"live collection failed: no counter rows for {kernel_full} ({sorted(vals)} found)"
+        if grid not in (None, items):
+            return None, f"live collection: the profiled child ran {grid} work items, this run {items}"
+        mean = {c: sum(v) / len(v) for c, v in vals.items()}
+        read_raw, written = mean["FETCH_SIZE"] * 1024.0, mean["WRITE_SIZE"] * 1024.0
+        entry = {"round": "live", "commit": None, "kernel": kernel_full, "n": args.n, "grid_workgroups": grid,
+                 "valu_busy": 4.0 * mean["SQ_ACTIVE_INST_VALU"] / 1024.0 / (mean["GRBM_GUI_ACTIVE"] / 8.0),
+                 "valu_cycles_per_inst": (4.0 * mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_INSTS_VALU"]) if mean.get("SQ_INSTS_VALU") else None,
+                 "force_kernel_hbm_bytes_per_launch": 2.0 * read_raw + written, "read_bytes_raw_FETCH_SIZE": read_raw,
+                 "read_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request)", "write_bytes_WRITE_SIZE": written,
+                 "launches_per_pass": min(len(v) for v in vals.values())}
+        return entry, "live"
+    except Exception as e:       # noqa: BLE001 - an optional measurement: never the reason a bench line is lost
+        return None, f"live collection failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(ic, n, target_s=10.0):
     """The CPU figures beside the GPU number, on a bounded i-slice of the same workload (all n j-particles):
     * kind "reference" — the compiled reference's OWN pairwise loop (Quadtree::acc, Quadtree.hpp:113-155, driven as a
@@ -386,6 +450,9 @@ def parse_args(argv=None):
                          "on (NB_FLAG_MASS_SCALING), measured (NB_FLAG_MASS_SCALING_MEASURED: the library measures at upload whether that is harmless "
                          "for these bodies; unsharded handles)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed general-mass secondary measurement")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="one GPU: do not collect this run's own PMC figures (three short `rocprofv3 --pmc` child runs of this command after the "
+                         "timed region: roofline.valu_busy / traffic of THIS box); the committed record of profiles/hbm_traffic.json is then used")
     ap.add_argument("--chunks-per-item", type=int, default=0, help="symmetric kernel: force nb_params.sym_chunks_per_item (tuning sweeps)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use GPU (LOCAL_RANK mod device_count)")
     ap.add_argument("--no-parity-check", action="store_true",
@@ -570,6 +637,12 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             book = {}
     kernel_full = kernel_instantiation(inner.describe(), args.precision, args.dims, args.rsqrt) if not sharded else None
     pmc, pmc_status = pmc_lookup(book, kernel_full, n, info["items"])
+    live, live_status = secondary.get("live_pmc") or (None, None)
+    committed = pmc                                   # what the committed record says, kept beside a live figure as a cross-check
+    if live is not None:
+        pmc, pmc_status = live, "live"
+    elif live_status:
+        pmc_status = f"{pmc_status} ({live_status})"
     pmc_ok = pmc is not None
     pmc = pmc or {}
     traffic_pmc = pmc.get("force_kernel_hbm_bytes_per_launch") if pmc_ok else None
@@ -644,13 +717,19 @@ def make_line(args, n, world, sim, m, sustained=None, secondary=None):
             "executed_frac": executed / peak if executed else None,
             "executed_flop_per_unordered_pair": ex["sym"][0 if um else 1] if symmetric else None,
             "valu_busy": pmc.get("valu_busy") if pmc_ok else None,
-            "valu_busy_source": ("profiles/hbm_traffic.json: a separate rocprofv3 --pmc run of this command on ANOTHER MI355X box, "
-                                 "not a measurement of this run") if pmc_ok else None,
+            "valu_busy_source": (("LIVE: separate rocprofv3 --pmc passes of this command (3 steps, child processes) on THIS box, run after the timed "
+                                  "region of this very invocation") if pmc_status == "live" else
+                                 ("profiles/hbm_traffic.json: a separate rocprofv3 --pmc run of this command on ANOTHER MI355X box, "
+                                  "not a measurement of this run") if pmc_ok else None),
+            "valu_busy_committed": (committed or {}).get("valu_busy") if pmc_status == "live" else None,
+            "traffic_committed": (committed or {}).get("force_kernel_hbm_bytes_per_launch") if pmc_status == "live" else None,
+            "valu_cycles_per_inst": pmc.get("valu_cycles_per_inst") if pmc_ok else None,
             "pmc_status": pmc_status,
             "pmc_commit": pmc.get("commit") if pmc_ok else None,
             "kernel_instantiation": kernel_full,
             "traffic": traffic_reported,
-            "traffic_source": ("PMC: profiles/hbm_traffic.json (separate rocprofv3 --pmc passes of this command on an MI355X: FETCH_SIZE x2 "
+            "traffic_source": (("PMC, LIVE on this box in this run" if pmc_status == "live" else "PMC: profiles/hbm_traffic.json") +
+                               " (separate rocprofv3 --pmc passes of this command on an MI355X: FETCH_SIZE x2 "
                                "+ WRITE_SIZE per launch of the force kernel)" if traffic_pmc else
                                "null: no PMC record of exactly this kernel instantiation, N and work plan is kept (pmc_status); the work plan's own "
                                "estimate is traffic_plan (stationary slab rows + travelling partials written once per launch + positions read once)"),
@@ -1226,6 +1305,9 @@ def main() -> None:
             # north_star's literal kernel design — one-sided, j-particles staged through LDS tiles of 256 — on the same workload
             secondary["lds_tiled"] = second(steps=max(4, args.steps // 4), symmetry=False, uniform_mass=not args.general_mass)
 
+    if not args.no_live_pmc and not args.no_secondary and not args.no_kernel_events:
+        # this run's own counters, on this box: after everything that is timed, before the CPU baseline
+        secondary["live_pmc"] = live_pmc(args, kernel_instantiation(sim.describe(), args.precision, args.dims, args.rsqrt), sim.sym_info()["items"])
     line = make_line(args, n, 1, sim, m, sustained, secondary)
     value = line["value"]
     if not args.no_secondary and args.dims == 2:

@@ -27,11 +27,11 @@ for what in "$@"; do
     cmain)  stage 300 gpurun_out/cmain.log ./build/nbody_main -n 262144 -s 20; tail -5 gpurun_out/cmain.log ;;
     prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
             rm -rf gpurun_out/prof
-            stage 600 gpurun_out/rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+            stage 600 gpurun_out/rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-pmc
             tail -3 gpurun_out/rocprof_stats.log; find gpurun_out/prof -name '*stats*' | head ;;
     prof64) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
             rm -rf gpurun_out/prof64
-            stage 600 gpurun_out/rocprof_stats64.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof64 -- python3 bench.py --precision fp64 --steps 10 --warmup 2 --no-cpu-baseline
+            stage 600 gpurun_out/rocprof_stats64.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof64 -- python3 bench.py --precision fp64 --steps 10 --warmup 2 --no-cpu-baseline --no-live-pmc
             tail -3 gpurun_out/rocprof_stats64.log; find gpurun_out/prof64 -name '*stats*' | head ;;
     bench64) stage 300 gpurun_out/bench64.log python bench.py --precision fp64 --steps 20 --warmup 3 --no-cpu-baseline; tail -1 gpurun_out/bench64.log ;;
     pmc)    # PMC_ARGS = extra bench.py arguments (another N, --general-mass ...), PMC_DIR = where the passes go (default gpurun_out/pmc)
@@ -42,7 +42,7 @@ for what in "$@"; do
                        "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS" \
                        "GRBM_GUI_ACTIVE GRBM_COUNT FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
               tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-              stage 300 gpurun_out/pmc_$tag.log rocprofv3 --pmc $set --output-format csv -d $pmcdir/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sustained --no-secondary ${PMC_ARGS:-}
+              stage 300 gpurun_out/pmc_$tag.log rocprofv3 --pmc $set --output-format csv -d $pmcdir/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sustained --no-secondary --no-live-pmc ${PMC_ARGS:-}
             done
             find $pmcdir -name '*counter_collection.csv' | head ;;
     *) echo "unknown stage $what" ;;
