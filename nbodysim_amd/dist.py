@@ -461,10 +461,15 @@ class DistributedSimulation:
         self._defer_errors = False                     # start-up trials: wait() keeps such a failure pending until the trial's collectives are through
 
         extra: dict = {}
+        #: a host that stages its candidates (bench.run_sharded: torch-driven tuning first, then ONE C-loop challenger) asks here
+        #: whether the library's own RCCL loop can be a challenger at all (RCCL process group), and what the timing chose beside
+        #: the protocol (``chosen_extra``: the late-item share), so that the challenger runs the same configuration
+        self.c_loop_available = bool(self._multi and dist.is_initialized() and dist.get_backend(group) == "nccl")
         if self._multi and (protocol == "tune" or driver == "tune"):
             protocol, extra, driver = self._tune(bodies, tune_steps, tune_dt, driver, None if protocol == "tune" else protocol)
         elif protocol == "tune":
             protocol = "auto"
+        self.chosen_extra = dict(extra)
         if driver == "tune":
             driver = "torch"
         self._create(bodies, protocol, extra, driver)

@@ -13,7 +13,8 @@ Faults are injected by name:  fault = (kind, where, rank)
                       the one after the timed steps does not
     Several faults at once: a tuple of such triples.
     where  the configuration it hits: "allgather/torch" (the safe-first one), "tune:<candidate>" (a trial of the start-up
-           timing) or "final" (the tuned configuration's own run)
+           timing), "final" (the tuned configuration's own run) or "c-loop" (the C-loop challenger of bench.run_sharded's
+           stage 2b; the stand-in offers one when NB_STANDIN_C_LOOP=1)
 """
 import sys
 import time
@@ -85,6 +86,11 @@ class StandinSharded:
         self.fault, self.where = fault, where
         self.tuning = None
         self.sim = StandinInner()
+        import os
+        self.c_loop_available = os.environ.get("NB_STANDIN_C_LOOP") == "1"      # pretend the library's own loop can challenge (bench.run_sharded, stage 2b)
+        self.chosen_extra = {}
+        if driver == "c":
+            self.where = "c-loop"
         if protocol == "tune" or driver == "tune":
             protocol, driver = self._tune()
             self.where = "final"
@@ -154,12 +160,14 @@ class StandinSharded:
             self.vy = (self.vy + ay[lo:hi] * dt32).astype(np.float32)
             nxt = self.pos[self.cur ^ 1]
             self.steps_done += 1
+            if self.where == "allgather/torch":
+                time.sleep(0.02)       # the plain protocol is the slow one, as on hardware: which line is the better fallback is then not this CPU's noise
             scale = np.float32(1.001) if (self._hit("corrupt") or (self._hit("corrupt_late") and self.steps_done > 2)) else np.float32(1.0)
             nxt[lo:hi, 0] = self.torch.from_numpy(((full[lo:hi, 0] + self.vx * dt32) * scale).astype(np.float32))
             nxt[lo:hi, 1] = self.torch.from_numpy(((full[lo:hi, 1] + self.vy * dt32) * scale).astype(np.float32))
             self.cur ^= 1
             self.pending = self._exchange()
-        if self._hit("hang") and self.where == "final":
+        if self._hit("hang") and self.where in ("final", "c-loop"):
             time.sleep(3600)
 
     def _exchange(self):
@@ -220,8 +228,8 @@ def bench_worker(rank, world, port, n, fault, extra_args=()):
                              "--no-kernel-events", "--deadline", "60", *extra_args])
     flat = load_flat(n)
     status = bench.run_sharded(args, None, n, world, rank,
-                               make_sim=lambda protocol, driver: StandinSharded(flat, protocol, driver, fault,
-                                                                                "allgather/torch" if (protocol, driver) == ("allgather", "torch") else ""),
+                               make_sim=lambda protocol, driver, extra=None: StandinSharded(flat, protocol, driver, fault,
+                                                                                            "allgather/torch" if (protocol, driver) == ("allgather", "torch") else ""),
                                make_reference=lambda: Unsharded(flat), device_sync=lambda: None, barrier=dist.barrier)
     sys.stdout.flush()
     sys.stderr.flush()

@@ -384,6 +384,61 @@ def test_sigterm_before_anything_valid_was_measured_is_a_plain_failure():
     assert out.strip() == ""
 
 
+def _run_bench_with_c_loop(fault, timeout=150):
+    import json
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, {t!r}); import shard_standin as s; "
+            "s.bench_worker({{rank}}, 2, {port}, 256, {fault!r}, ('--candidate-deadline', '3'))").format(t=str(TESTS), port=port, fault=fault)
+    env = dict(os.environ, NB_STANDIN_C_LOOP="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(rank=r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    lines = [[json.loads(l) for l in out.splitlines() if l.startswith("{")] for out, _ in outs]
+    return [p.returncode for p in procs], lines, [e for _, e in outs]
+
+
+def test_the_c_loop_is_one_challenger_after_the_torch_driven_winner_was_measured():
+    """Round 6: staged flow.  The start-up timing runs over torch-driven candidates only; the winner's full, validated measurement
+    becomes the fallback line; then the library's C loop runs the SAME protocol as ONE challenger.  Here it passes and ties: the C
+    line is printed and carries both figures."""
+    rcs, lines, errs = _run_bench_with_c_loop(None)
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    ch = d["config"]["c_loop_challenger"]
+    assert ch["protocol"] == "allreduce" and ch["parity_check"]["ok"] is True and ch["ms_per_step"] > 0
+    if ch["won"]:        # (the stand-in's "C loop" is the same CPU engine: which of two equal runs is 1 % faster is this machine's noise)
+        assert d["config"]["driver"] == "c" and d["config"]["torch_driven"]["driver"] == "torch" and d["config"]["torch_driven"]["ms_per_step"] > 0
+        assert d["value"] == ch["value"] >= 0.99 * d["config"]["torch_driven"]["value"]
+    else:
+        assert d["config"]["driver"] == "torch" and "slower than the torch-driven loop" in ch["why_not"] and ch["value"] < 0.99 * d["value"]
+    assert d["fallback"] == {"used": False} and d["parity_check"]["ok"] is True and d["config"]["safe_first"]["parity_check"]["ok"] is True
+    assert "Trying the library's C loop on the same protocol" in errs[0] and "C loop" in d["config"]["driver_choice"]
+    assert set(d["config"]["protocol_tuning"]["ms_per_step"]) == {"allgather", "allreduce", "symmetric"}          # no c: candidates in the timing any more
+
+
+def test_a_c_loop_that_hangs_costs_the_c_figure_not_the_torch_driven_result():
+    """... and when the challenger hangs (a communicator that never forms, a collective that never completes on this node), the line
+    printed is the TORCH-DRIVEN WINNER's — the allreduce configuration here, not the all-gather one measured first —, status 0."""
+    t0 = time.time()
+    rcs, lines, errs = _run_bench_with_c_loop(("hang", "c-loop", 1))
+    assert rcs == [0, 0], errs
+    assert len(lines[0]) == 1 and lines[1] == []
+    d = lines[0][0]
+    assert d["fallback"]["used"] is True and "C-loop challenger" in d["fallback"]["phase"]
+    assert d["config"]["protocol"] == "allreduce" and d["parity_check"]["ok"] is True and d["parity_check"]["after_timed_region"]["ok"] is True
+    assert d["config"]["safe_first"]["protocol"] == "allgather" and d["value"] > d["config"]["safe_first"]["value"]
+    assert "now the fallback line" in errs[0] and all("expired while running the C-loop challenger (allreduce protocol)" in e for e in errs)
+    assert time.time() - t0 < 60                        # the challenger's own deadline, not the whole run's
+
+
+def test_a_wrong_c_loop_is_reported_and_not_taken():
+    rcs, lines, errs = _run_bench_with_c_loop(("corrupt", "c-loop", 0))
+    assert rcs == [0, 0], errs
+    d = lines[0][0]
+    ch = d["config"]["c_loop_challenger"]
+    assert ch["won"] is False and "parity_check failed" in ch["why_not"] and d["config"]["driver"] == "torch"
+    assert d["fallback"] == {"used": False} and d["parity_check"]["ok"] is True and "C loop not taken" in d["config"]["driver_choice"]
+
+
 def test_parity_helpers_alone():
     sys.path.insert(0, str(ROOT))
     from nbodysim_amd.dist import ShardPlan, compare_with_unsharded, gather_rows, max_rel, state_rows
