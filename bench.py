@@ -573,7 +573,8 @@ def driver_reason(sim):
     c_ms, t_ms = ms.get("c:" + proto), ms.get(proto)
     fmt = lambda v: "unavailable" if v is None else f"{v:.3f} ms/step"
     if not any(k.startswith("c:") for k in ms):
-        return f"torch: the library's C loop was not a candidate ({'no RCCL process group (gloo rehearsal)' if drv == 'torch' else 'driver forced'})"
+        return ("torch: the start-up timing ran over torch-driven candidates; the library's C loop challenges its winner afterwards where there is "
+                "an RCCL process group (config.c_loop_challenger)")
     vs = (val.get("c:" + proto) or {}).get("vs_torch_loop")
     why = f"C loop {fmt(c_ms)} vs torch-driven {fmt(t_ms)} in the start-up timing of the '{proto}' protocol"
     if vs:

@@ -82,7 +82,7 @@ def test_the_line_says_which_host_loop_won_and_why():
     why = b.driver_reason(s)
     assert why.startswith("c: C loop 0.980 ms/step vs torch-driven 1.050 ms/step") and "bit-identical" in why and "c:allreduce" in why
     s.driver, s.tuning = "torch", {"ms_per_step": {"allgather": 1.6, "symmetric": 1.05}, "validation": {}, "chosen": "symmetric", "failed": {}}
-    assert b.driver_reason(s).startswith("torch: the library's C loop was not a candidate")
+    assert b.driver_reason(s).startswith("torch: the start-up timing ran over torch-driven candidates")
     s.tuning = None
     assert "named on the command line" in b.driver_reason(s)
     assert b.parse_args([]).driver == "tune" and b.parse_args([]).protocol == "tune"        # the defaults of a node run
