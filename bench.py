@@ -1123,6 +1123,9 @@ def ranks_command(argv, gpus, port, script=None, python=None):
             "--master-port", str(port), str(script or Path(__file__).resolve()), *fwd]
 
 
+LAST_LAUNCH = {"lines": 0, "stopped": False, "seconds": 0.0}      # what the last launch_ranks call saw (main() decides on a second attempt from it)
+
+
 def launch_ranks(argv, gpus, deadline_s=0.0, out=None, command=None) -> int:
     """Start the N ranks as CHILD processes and wait for them; returns the status this process should end with.
     * the parent never imports torch or the library: nothing here touches a GPU, and nothing is exec'ed in place;
@@ -1134,6 +1137,8 @@ def launch_ranks(argv, gpus, deadline_s=0.0, out=None, command=None) -> int:
     Status: the launcher child's — except that a run which relayed a bench line and was stopped by a signal ends 0 (the
     line IS the result; the ranks that held no line died of the signal, which torch.distributed.run reports as a failure)."""
     out = out or sys.stdout
+    t_start = time.time()
+    LAST_LAUNCH.update({"lines": 0, "stopped": False, "seconds": 0.0})
     cmd = command or ranks_command(argv, gpus, _free_port())
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL shares device buffers through dmabuf IPC on this driver stack
@@ -1189,6 +1194,7 @@ def launch_ranks(argv, gpus, deadline_s=0.0, out=None, command=None) -> int:
             killer.cancel()
         for sg, h in previous.items():
             signal.signal(sg, h)
+    LAST_LAUNCH.update({"lines": lines, "stopped": stopped["by"] is not None, "seconds": time.time() - t_start})
     if stopped["by"] is not None and lines:
         return 0
     return rc if rc >= 0 else 128 - rc
@@ -1242,7 +1248,14 @@ def main() -> None:
     # one process drives all N handles through the library's C loop.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_sharded:
         if not args.one_process and torchrun_available():
-            raise SystemExit(launch_ranks(sys.argv[1:], args.gpus, args.deadline))
+            rc = launch_ranks(sys.argv[1:], args.gpus, args.deadline)
+            if rc != 0 and LAST_LAUNCH["lines"] == 0 and not LAST_LAUNCH["stopped"] and LAST_LAUNCH["seconds"] < 30.0:
+                # the ranks were gone within seconds and never got as far as a line: a rendezvous that did not form (a port taken between
+                # the probe and the bind) looks exactly like this; one more attempt, on another port, costs seconds
+                sys.stderr.write(f"[bench] the ranks ended with status {rc} after {LAST_LAUNCH['seconds']:.0f} s without a line: one more attempt\n")
+                sys.stderr.flush()
+                rc = launch_ranks(sys.argv[1:], args.gpus, args.deadline)
+            raise SystemExit(rc)
         if not args.one_process:
             sys.stderr.write("[bench] torch.distributed.run is not available: one process drives all ranks (nb_comm_create_all)\n")
         raise SystemExit(run_one_process(args))

@@ -184,6 +184,7 @@ def test_typed_without_a_launcher_the_ranks_start_as_children_even_here():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "4096"],
                        capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert "starting 2 ranks as child processes" in r.stderr and "--nproc-per-node=2" in r.stderr and "--nbodies 4096" in r.stderr
+    assert r.stderr.count("starting 2 ranks as child processes") == 2 and "one more attempt" in r.stderr      # ranks gone in seconds without a line: tried once more
     assert "must be launched with" not in r.stderr
     import torch
     if not torch.cuda.is_available():
