@@ -1215,7 +1215,7 @@ def run_one_process(args) -> int:
         raise SystemExit(f"--gpus {world} but this node shows {have} device(s) (--share-gpu rehearses the ranks on the devices there are)")
     devices = [r % have for r in range(world)]
     ic = nb.plummer_2d(n, SEED) if args.dims == 2 else nb.plummer_3d(n, SEED)
-    scaling = {"off": False, "on": True, "measured": "measured"}[args.mass_scaling]
+    scaling = {"off": False, "on": True, "measured": False}[args.mass_scaling]     # "measured" is for unsharded handles: the sharded run and its checker keep the same body
     physics = dict(eps=EPS, precision=args.precision, rsqrt=args.rsqrt, dims=args.dims, uniform_mass=not args.general_mass, mass_scaling=scaling)
     live = []
 
@@ -1284,6 +1284,11 @@ def main() -> None:
     rehearsal = args.rehearse_sharded and world == 1
     if world > 1 or rehearsal:
         import datetime
+
+        if scaling == "measured":      # the upload-time measurement exists for unsharded handles only: a sharded run and its unsharded checker
+            scaling = False            # must run the SAME pair body, so here it means the default, on both sides
+            if rank == 0:
+                sys.stderr.write("[bench] --mass-scaling measured applies to unsharded handles; this sharded run keeps both mass multiplies\n")
 
         import torch.distributed as dist
 
