@@ -861,7 +861,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
 
     emit = emit or (lambda text: print(text, flush=True))
     phase = {"now": "starting"}
-    state = {"safe_line": None, "printed": False}
+    state = {"safe_line": None, "first_line": None, "printed": False}
     lock = threading.Lock()
 
     def print_once(line) -> bool:
@@ -916,7 +916,7 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
                 # is only recorded in parity["ok"] — such a line must not become the fallback (it would be printed with status 0)
                 safe_valid = safe_m["parity"] is None or bool(safe_m["parity"]["ok"])
                 if safe_valid:
-                    state["safe_line"] = safe_line
+                    state["safe_line"] = state["first_line"] = safe_line
                 else:
                     state["safe_failed"] = (f"parity_check failed (allgather protocol, torch loop, after the timed region): "
                                             f"{safe_m['parity'].get('after_timed_region')}")
@@ -1024,6 +1024,23 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
             line["config"]["driver_choice"] = (f"{line['config']['driver']}: C loop {challenger.get('ms_per_step', float('nan')):.3f} ms/step vs torch-driven "
                                                f"{(line['config'].get('torch_driven') or line)['ms_per_step']:.3f} ms/step on the '{proto}' protocol, both full "
                                                f"measurements with the self-check" + ("" if challenger.get("won") else f"; C loop not taken: {challenger.get('why_not')}"))
+        # The line printed is the FASTEST of the full, validated measurements.  The start-up timing orders its candidates on a dozen steps
+        # each; if the configuration it chose then measures slower over W + K steps than the plain all-gather one did (a mis-ordered
+        # near-tie, a protocol that degrades over a longer run), the plain one's line goes out — and says what was tuned and lost.
+        first = state.get("first_line")
+        if first is not None and first["value"] > line["value"]:
+            chosen = dict(first)
+            chosen["config"] = dict(first["config"])
+            chosen["config"]["tuned_but_slower"] = {"protocol": line["config"].get("protocol"), "driver": line["config"].get("driver"),
+                                                    "ms_per_step": line["ms_per_step"], "value": line["value"],
+                                                    "c_loop_challenger": line["config"].get("c_loop_challenger")}
+            chosen["config"]["safe_first"] = line["config"].get("safe_first")
+            chosen["config"]["protocol_tuning"] = state.get("tuning")
+            chosen["fallback"] = {"used": False}
+            if rank == 0:
+                sys.stderr.write(f"[bench] the tuned configuration ({line['config'].get('protocol')}, {line['config'].get('driver')} loop) measured "
+                                 f"{line['ms_per_step']:.3f} ms/step, the all-gather one {first['ms_per_step']:.3f}: printing the faster, validated line\n")
+            line = chosen
         print_once(line)
     except ParityError as e:
         if rank == 0:
@@ -1185,9 +1202,13 @@ def launch_ranks(argv, gpus, deadline_s=0.0, out=None, command=None) -> int:
                 continue
             if not text:
                 break
-            out.write(text)
-            out.flush()
-            lines += text.lstrip().startswith("{")
+            if text.lstrip().startswith("{"):        # rank 0's line: the ONLY thing this process puts on stdout
+                out.write(text)
+                out.flush()
+                lines += 1
+            else:                                    # whatever else a rank or a library wrote to its stdout (gloo's connection notes ...)
+                sys.stderr.write(text)
+                sys.stderr.flush()
         rc = proc.wait()
     finally:
         if killer is not None:

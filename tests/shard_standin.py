@@ -89,6 +89,7 @@ class StandinSharded:
         import os
         self.c_loop_available = os.environ.get("NB_STANDIN_C_LOOP") == "1"      # pretend the library's own loop can challenge (bench.run_sharded, stage 2b)
         self.chosen_extra = {}
+        self._slow_final = os.environ.get("NB_STANDIN_SLOW_FINAL") == "1"
         if driver == "c":
             self.where = "c-loop"
         if protocol == "tune" or driver == "tune":
@@ -162,6 +163,8 @@ class StandinSharded:
             self.steps_done += 1
             if self.where == "allgather/torch":
                 time.sleep(0.02)       # the plain protocol is the slow one, as on hardware: which line is the better fallback is then not this CPU's noise
+            if self.where == "final" and self._slow_final:
+                time.sleep(0.08)       # ... unless a test wants the tuned configuration to lose its full measurement (NB_STANDIN_SLOW_FINAL=1)
             scale = np.float32(1.001) if (self._hit("corrupt") or (self._hit("corrupt_late") and self.steps_done > 2)) else np.float32(1.0)
             nxt[lo:hi, 0] = self.torch.from_numpy(((full[lo:hi, 0] + self.vx * dt32) * scale).astype(np.float32))
             nxt[lo:hi, 1] = self.torch.from_numpy(((full[lo:hi, 1] + self.vy * dt32) * scale).astype(np.float32))

@@ -138,8 +138,8 @@ def test_launcher_relays_the_line_and_returns_the_childrens_status():
     import io
     b = load_bench()
     out = io.StringIO()
-    rc = b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import sys; print('{\"value\": 1}'); sys.stderr.write('rank noise\\n')"])
-    assert rc == 0 and out.getvalue() == '{"value": 1}\n'
+    rc = b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import sys; print('[Gloo] a library note on stdout'); print('{\"value\": 1}'); sys.stderr.write('rank noise\\n')"])
+    assert rc == 0 and out.getvalue() == '{"value": 1}\n'            # only the line reaches stdout; anything else a rank printed there goes to stderr
     out = io.StringIO()
     assert b.launch_ranks([], 2, out=out, command=[sys.executable, "-c", "import sys; sys.exit(4)"]) == 4 and out.getvalue() == ""
     out = io.StringIO()          # a child killed by a signal is a failure, never a silent 0

@@ -384,6 +384,27 @@ def test_sigterm_before_anything_valid_was_measured_is_a_plain_failure():
     assert out.strip() == ""
 
 
+def test_the_line_printed_is_the_fastest_validated_full_measurement():
+    """The start-up timing orders candidates on a dozen steps each.  If its choice then measures SLOWER over the W + K timed steps than
+    the plain all-gather configuration did, the all-gather line is printed (fallback.used stays false: nothing failed) and says what
+    was tuned and lost."""
+    import json
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, {t!r}); import shard_standin as s; "
+            "s.bench_worker({{rank}}, 2, {port}, 256, None, ())").format(t=str(TESTS), port=port)
+    env = dict(os.environ, NB_STANDIN_SLOW_FINAL="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(rank=r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=150) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [e[-600:] for _, e in outs]
+    lines = [json.loads(l) for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]        # (gloo itself prints a connection note on stdout)
+    d = lines[0]
+    slow = d["config"]["tuned_but_slower"]
+    assert d["config"]["protocol"] == "allgather" and d["fallback"] == {"used": False} and d["parity_check"]["ok"] is True
+    assert slow["protocol"] == "allreduce" and slow["value"] < d["value"] and d["config"]["protocol_tuning"]["chosen"] == "allreduce"
+    assert d["config"]["safe_first"]["protocol"] == "allgather" and "printing the faster, validated line" in outs[0][1]
+
+
 def _run_bench_with_c_loop(fault, timeout=150):
     import json
     port = _free_port()
