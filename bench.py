@@ -347,7 +347,7 @@ def live_pmc(args, kernel_full, items, timeout_s=75.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def cpu_baseline(ic, n, target_s=10.0):
+def cpu_baseline(ic, n, target_s=6.0):
     """The CPU figures beside the GPU number, on a bounded i-slice of the same workload (all n j-particles):
     * kind "reference" — the compiled reference's OWN pairwise loop (Quadtree::acc, Quadtree.hpp:113-155, driven as a
       direct sum through a single-leaf tree and fanned over std::async tasks like Simulation::attract) from

@@ -67,6 +67,49 @@ __device__ __forceinline__ void store16(float4 *p, float4 v)
 }
 
 // ---------------------------------------------------------------------------
+// expf_libm — the soft boundary of Simulation::iterate calls std::exp on a float (Simulation.hpp:147): glibc's expf.  The device's
+// own expf is a different algorithm (bodies beyond the boundary came out 1e-7 apart: the one place a `sequential` + `quake` step was
+// not bit-identical to the compiled reference).  This is glibc 2.35's algorithm restated (sysdeps/ieee754/flt-32/e_expf.c, from ARM's
+// optimized routines): exp(x) = 2^(k/32) 2^(r/32) with k = round(32 x / ln 2) taken from the low bits of (z + 1.5 * 2^52), a 32-entry
+// table of 2^(i/32) and a cubic in double, rounded to float once.  Pinned on the host against libm's expf, bit for bit, over 2.4e8
+// floats covering the whole finite range (tests/test_oracle.py: the same statements compiled by gcc, with and without FMA
+// contraction — both agree with libm everywhere, so the contraction the device compiler chooses does not matter).
+// Table: asuint64(2^(i/32)) - (i << 47), correctly rounded.
+// ---------------------------------------------------------------------------
+__device__ static const uint64_t EXPF_TAB[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL
+};
+
+__device__ __forceinline__ float expf_libm(float x)
+{
+#pragma clang fp contract(off)                                  // only the three explicit fma below: z + 1.5 * 2^52 must see the ROUNDED product
+    if (x != x) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();          // overflow (glibc: __math_oflowf)
+    if (x < -0x1.9fe368p6f) return 0.0f;                      // below the smallest subnormal
+    const double z = (0x1.71547652b82fep+0 * 32.0) * (double)x;
+    double kd = z + 0x1.8p+52;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= 0x1.8p+52;
+    const double r = z - kd;
+    const uint64_t t = EXPF_TAB[ki & 31u] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double p = __builtin_fma(0x1.c6af84b912394p-5 / 32768.0, r, 0x1.ebfce50fac4f3p-3 / 1024.0);
+    double y = __builtin_fma(0x1.62e42ff0c52d6p-1 / 32.0, r, 1.0);
+    y = __builtin_fma(p, r * r, y);
+    return (float)(y * sc);
+}
+
+__device__ __forceinline__ float exp_like_reference(float x) { return expf_libm(x); }
+__device__ __forceinline__ double exp_like_reference(double x) { return exp(x); }      // fp64 handles: no reference to match
+
+// ---------------------------------------------------------------------------
 // kick_drift_one — Simulation::iterate after attract(), Simulation.hpp:129-163, for ONE owned
 // particle whose summed acceleration is `a`: acc <- a; v += a dt; [clamp :133-137];
 // [soft boundary :140-155]; x_next = x + v dt.  STRICT keeps every operation individually
@@ -112,7 +155,7 @@ void kick_drift_loaded(typename vec2_of<real>::type a, typename vec2_of<real>::t
         if (d2 > SOFT_BOUNDARY * SOFT_BOUNDARY) {
             const real dist = sqrt(d2);
             const real ratio = dist / SOFT_BOUNDARY;
-            const real force = (real)0.9f * exp(ratio - (real)1.0);
+            const real force = (real)0.9f * exp_like_reference(ratio - (real)1.0);   // std::exp(float) = glibc's expf, restated above
             const real k = (real)-1.0 / dist;
             const real fdt = force * dt_kick;
             v.x += (x.x * k) * fdt;
