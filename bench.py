@@ -424,14 +424,15 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--protocol", default="tune", choices=["tune", "auto", "symmetric", "allreduce", "allgather"],
-                    help="multi-GPU exchange: tune (default) times a few steps of the symmetric pair split (reduce-scatter + "
-                         "all-gather) and of north_star's all-gather protocol before the timed region and keeps the faster; "
-                         "the others force one")
+                    help="multi-GPU exchange: tune (default) times a few validated steps of north_star's all-gather protocol, of the replicated "
+                         "all-reduce protocol and of the symmetric pair split (reduce-scatter + all-gather; with and without held-back late items) "
+                         "before the timed region and keeps the fastest; the others force one")
     ap.add_argument("--driver", default="tune", choices=["tune", "torch", "c"],
                     help="multi-GPU step loop: c = the library's own RCCL loop (nb_comm_step: one foreign call for all steps; north_star: "
                          "'host code stays in C'); torch = collectives through torch.distributed between the library's split-step calls; "
-                         "tune (default) = both are candidates of the start-up timing, and a C-loop candidate may only win after its trial "
-                         "reproduced the torch-driven trial of the same protocol bit for bit and passed the unsharded check")
+                         "tune (default) = staged: the start-up timing runs over torch-driven candidates, the winner is measured in full and "
+                         "becomes the fallback line, then the C loop runs the same protocol as ONE challenger under its own deadline and is "
+                         "printed if it passed the self-check and is not more than 1 %% slower")
     ap.add_argument("--deadline", type=float, default=420.0,
                     help="seconds the whole multi-GPU run may take before the rank prints the phase it is in and exits with status 3 "
                          "— or, once the safe-first configuration has been measured, prints THAT line and exits 0 (a stuck collective "
