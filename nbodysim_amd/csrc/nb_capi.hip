@@ -471,8 +471,10 @@ static int copy_d2h(nb_sim *s, void *dst, const void *src, size_t bytes, hipStre
     }
     { const int rc = ensure_bounce(s); if (rc) return rc; }
     if (stage) {
-        // whole transfer staged: BOUNCE_SLOTS equal pieces, one event each
-        const size_t piece = ((bytes + BOUNCE_SLOTS - 1) / BOUNCE_SLOTS + 63) & ~(size_t)63;
+        // whole transfer staged: BOUNCE_SLOTS equal pieces, one event each — one piece where the transfer is so short (<= 1 MiB: the
+        // positions of a small system, nb_sync_positions) that three more DMA launches and events cost more than the overlap buys
+        const size_t pieces = bytes <= ((size_t)1 << 20) ? 1 : BOUNCE_SLOTS;
+        const size_t piece = ((bytes + pieces - 1) / pieces + 63) & ~(size_t)63;
         size_t k = 0;
         for (size_t off = 0; off < bytes; off += piece, ++k) {
             const size_t len = bytes - off < piece ? bytes - off : piece;

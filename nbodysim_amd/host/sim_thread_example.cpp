@@ -81,9 +81,11 @@ int main(int argc, char **argv)
         const size_t n = reference ? 25000 : (size_t)atol(argv[2]);
         const int frames = argc > 3 ? atoi(argv[3]) : 200;
         if (!reference) SIMULATION_DT.store(1e-3f);
-        const char *names[5] = {"step_copy", "step", "overlapped_copy", "step_wait", "resident"};
-        double ms[5] = {0, 0, 0, 0, 0};
-        for (int mode = 0; mode < 5; ++mode) {
+        //   positions        nb_step(1) + nb_sync_positions            (a viewer that draws positions only: 8 B per body instead of 64)
+        const char *names[6] = {"step_copy", "step", "overlapped_copy", "step_wait", "resident", "positions"};
+        double ms[6] = {0, 0, 0, 0, 0, 0};
+        std::vector<float> xy(2 * n);
+        for (int mode = 0; mode < 6; ++mode) {
             std::unique_ptr<Simulation> sim;
             if (reference) sim.reset(new Simulation());
             else {
@@ -99,13 +101,14 @@ int main(int argc, char **argv)
             else for (int f = 0; f < frames; ++f) {
                 if (mode == 0 || mode == 1) sim->step();
                 else if (mode == 2) sim->step_overlapped();
+                else if (mode == 5) { sim->advance(1); if (nb_sync_positions(sim->handle(), xy.data()) != NB_OK) return 1; }
                 else { sim->advance(1); if (nb_wait(sim->handle()) != NB_OK) return 1; }
                 if (mode == 0 || mode == 2) { std::lock_guard<std::mutex> lock(UPDATE_LOCK); SHARED_BODIES = sim->bodies; }
             }
             ms[mode] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
         }
         std::printf("{\"workload\": \"%s\", \"n\": %zu, \"frames\": %d, \"bytes_per_frame\": %zu", reference ? "Simulation() default start" : "plummer_2d", n, frames, n * sizeof(Body));
-        for (int k = 0; k < 5; ++k) std::printf(", \"%s_ms\": %.4f", names[k], ms[k]);
+        for (int k = 0; k < 6; ++k) std::printf(", \"%s_ms\": %.4f", names[k], ms[k]);
         std::printf("}\n");
         return 0;
     }
