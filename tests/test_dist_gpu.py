@@ -440,3 +440,38 @@ def test_a_compute_failure_on_one_rank_inside_a_candidate_strands_nobody(tmp_pat
     pos = np.concatenate([np.load(tmp_path / f"fpos_{r}.npy") for r in range(world)])
     ref, _, _ = _reference(n, 4, "fp32")
     assert _rel(pos, ref.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize("protocol,precision,world", [("allgather", "fp32", 3), ("symmetric", "fp32", 4), ("allreduce", "fp32", 4), ("symmetric", "fp64", 2)])
+def test_one_process_drives_every_rank_and_follows_the_unsharded_handle(protocol, precision, world):
+    """nbodysim_amd.local_ranks.LocalRanksSimulation — what `bench.py --gpus N` falls back to where torch.distributed.run is missing:
+    ONE process, `world` sharded handles, no torch, no process group.  On a node the handles sit on different devices and the
+    library's RCCL loop (nb_comm_create_all / nb_comm_step) runs them; here they share the one GPU and the library's in-process exchange
+    stands in for the transport (RCCL takes one rank per device).  Every protocol must follow ONE unsharded handle to north_star's
+    tolerance; the replicated protocol keeps bit-identical replicas; a ragged split (3 ranks) works in the all-gather protocol."""
+    from nbodysim_amd.local_ranks import LocalRanksSimulation
+    n, steps, dt = (65536 if world != 3 else 50000), 6, 1e-3
+    ic = nb.plummer_2d(n, 21)
+    with nb.Simulation(ic, eps=0.02, precision=precision) as ref:
+        ref.advance(steps, dt)
+        want = ref.sync().copy()
+        e_want = sum(ref.energy())
+    with LocalRanksSimulation(ic, world, devices=[0] * world, protocol=protocol, eps=0.02, precision=precision) as sim:
+        assert sim.transport == "in-process" and sim.protocol == protocol and len(sim.sims) == world and sim.plan.n == n
+        sim.advance(2, dt)
+        sim.advance(steps - 2, dt)
+        sim.wait()
+        got = sim.sync()
+        e_got = sum(sim.energy())
+        assert sim.frame == steps and sim.replicas_identical()
+        rows = sim.owned_rows()
+    assert got.shape == want.shape and rows.shape == (n, 4)
+    tol = 1e-5 if precision == "fp32" else 2e-7            # fp64 state comes back through the float Body record
+    den = np.linalg.norm(want["pos"], axis=1)
+    assert np.max(np.linalg.norm(got["pos"].astype(np.float64) - want["pos"], axis=1) / np.where(den > 0, den, 1)) < tol
+    assert abs(e_got - e_want) < (1e-5 if precision == "fp32" else 1e-10) * abs(e_want)
+    with pytest.raises(ValueError):
+        LocalRanksSimulation(ic, 1)
+    if protocol == "symmetric":
+        with pytest.raises(RuntimeError, match="not eligible"):
+            LocalRanksSimulation(nb.plummer_2d(4096, 1), world, devices=[0] * world, protocol="symmetric", eps=0.02)
