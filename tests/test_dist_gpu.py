@@ -449,6 +449,7 @@ def test_one_process_drives_every_rank_and_follows_the_unsharded_handle(protocol
     library's RCCL loop (nb_comm_create_all / nb_comm_step) runs them; here they share the one GPU and the library's in-process exchange
     stands in for the transport (RCCL takes one rank per device).  Every protocol must follow ONE unsharded handle to north_star's
     tolerance; the replicated protocol keeps bit-identical replicas; a ragged split (3 ranks) works in the all-gather protocol."""
+    import nbodysim_amd as nb
     from nbodysim_amd.local_ranks import LocalRanksSimulation
     n, steps, dt = (65536 if world != 3 else 50000), 6, 1e-3
     ic = nb.plummer_2d(n, 21)
