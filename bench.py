@@ -1270,6 +1270,7 @@ def main() -> None:
     # one process drives all N handles through the library's C loop.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_sharded:
         if not args.one_process and torchrun_available():
+            t_launch = time.time()
             rc = launch_ranks(sys.argv[1:], args.gpus, args.deadline)
             if rc != 0 and LAST_LAUNCH["lines"] == 0 and not LAST_LAUNCH["stopped"] and LAST_LAUNCH["seconds"] < 30.0:
                 # the ranks were gone within seconds and never got as far as a line: a rendezvous that did not form (a port taken between
@@ -1277,6 +1278,14 @@ def main() -> None:
                 sys.stderr.write(f"[bench] the ranks ended with status {rc} after {LAST_LAUNCH['seconds']:.0f} s without a line: one more attempt\n")
                 sys.stderr.flush()
                 rc = launch_ranks(sys.argv[1:], args.gpus, args.deadline)
+            if rc != 0 and LAST_LAUNCH["lines"] == 0 and not LAST_LAUNCH["stopped"] and time.time() - t_launch < 450.0:
+                # one process per GPU did not get as far as a line (a process group that would not form, IPC between the ranks refused ...):
+                # the library's own loop needs neither — ONE process, peer access instead of IPC, ncclCommInitAll instead of a rendezvous.
+                # This process has not touched a GPU yet; it does now (no exec involved).
+                sys.stderr.write(f"[bench] the launched ranks ended with status {rc} and no line: falling back to ONE process driving all "
+                                 f"{args.gpus} handles (nb_comm_create_all)\n")
+                sys.stderr.flush()
+                raise SystemExit(run_one_process(args))
             raise SystemExit(rc)
         if not args.one_process:
             sys.stderr.write("[bench] torch.distributed.run is not available: one process drives all ranks (nb_comm_create_all)\n")

@@ -190,3 +190,5 @@ def test_typed_without_a_launcher_the_ranks_start_as_children_even_here():
     if not torch.cuda.is_available():
         # (the launcher tears the other rank down as soon as the first one fails: one or two refusals reach stderr)
         assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 1 and r.stdout.strip() == ""
+        # ... and the last resort was tried too: ONE process driving all handles (which, here, finds no GPU either)
+        assert "falling back to ONE process driving all 2 handles" in r.stderr and r.stderr.rstrip().endswith("the hot path has no CPU fallback")
