@@ -187,3 +187,19 @@ def test_bench_gpus_2_in_one_process_through_the_librarys_own_loop():
     assert t["chosen"] == d["config"]["protocol"] and set(t["ms_per_step"]) == {"allgather", "allreduce", "symmetric"}
     assert abs(d["value"] - 32768.0 ** 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert abs(d["energy"]["rel_drift"]) < 1e-3
+
+
+def test_launched_ranks_that_cannot_form_a_group_fall_back_to_one_process():
+    """The whole last-resort chain of `bench.py --gpus N` typed without a launcher, end to end: on this one GPU the two launched ranks
+    cannot form an RCCL process group (RCCL: "Duplicate GPU detected") and end without a line; the launcher tries once more on
+    another port, then ONE process drives both handles itself (here over the in-process exchange: the handles share the GPU) — and
+    the run ends with a validated line and status 0.  On a node the same chain covers a process group that will not form."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "1", "--nbodies", "32768",
+                        "--no-sustained", "--deadline", "120"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip() == lines[0]                     # nothing but the line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity_check"]["ok"] is True and d["fallback"] == {"used": False} and "in-process" in d["config"]["backend"]
+    assert r.stderr.count("starting 2 ranks as child processes") == 2 and "one more attempt" in r.stderr
+    assert "falling back to ONE process driving all 2 handles" in r.stderr
