@@ -1021,6 +1021,12 @@ def run_sharded(args, ic, n, world, rank, make_sim, make_reference, device_sync,
                 challenger.update({"won": False, "why_not": str(e)})
                 if rank == 0:
                     sys.stderr.write(f"[bench] C-loop challenger: {e}\n")
+            except RuntimeError as e:          # "... could not be formed on every rank" / "... not the same sharded plan": raised by EVERY rank
+                if "on every rank" not in str(e) and "did not build the same sharded plan" not in str(e):     # together (agreed inside the host)
+                    raise
+                challenger.update({"won": False, "why_not": str(e)})
+                if rank == 0:
+                    sys.stderr.write(f"[bench] C-loop challenger: {e}\n")
             line["config"]["c_loop_challenger"] = challenger
             line["config"]["driver_choice"] = (f"{line['config']['driver']}: C loop {challenger.get('ms_per_step', float('nan')):.3f} ms/step vs torch-driven "
                                                f"{(line['config'].get('torch_driven') or line)['ms_per_step']:.3f} ms/step on the '{proto}' protocol, both full "
