@@ -287,7 +287,7 @@ def pmc_lookup(book, kernel_full, n, items):
     return None, "none"
 
 
-def live_pmc(args, kernel_full, items, timeout_s=75.0):
+def live_pmc(args, kernel_full, items, timeout_s=45.0):
     """The PMC figures of THIS run's dominant kernel, collected on THIS box after the timed region: three separate `rocprofv3 --pmc`
     passes (MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled on gfx950)
     of this very command in its shortest form (3 steps, nothing but the step loop) as CHILD processes — `rocprofv3 ... -- python3
