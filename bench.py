@@ -314,12 +314,19 @@ def live_pmc(args, kernel_full, items, timeout_s=45.0):
     try:
         for k, counters in enumerate(sets):
             cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", f"{tmp}/{k}", "--", *child]
+            # its own session: on a time-out the whole group goes (the profiler AND the child it started), nothing is left on the GPU
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                out, _ = proc.communicate(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                proc.wait()
                 return None, f"live collection failed: pass {k} ({' '.join(counters)}) exceeded {timeout_s:.0f} s"
-            if r.returncode != 0:
-                return None, f"live collection failed: pass {k} ({' '.join(counters)}) ended with status {r.returncode}: {(r.stderr or r.stdout)[-160:]!r}"
+            if proc.returncode != 0:
+                return None, f"live collection failed: pass {k} ({' '.join(counters)}) ended with status {proc.returncode}: {(out or '')[-160:]!r}"
         vals, grid = {}, None
         for f in glob.glob(f"{tmp}/*/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
